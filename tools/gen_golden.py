@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE itself (runs in the build container only).
+
+Imports ``/root/reference/model.py`` (needs the single constant ``omegaconf.MISSING``,
+``model.py:6``; omegaconf is not installed, so a 2-attribute in-process module stands
+in for it, as SURVEY 8c documents), loads this project's seeded random-init weights
+(``vectorquantizedcpc_amd.synth``) through ``load_state_dict`` and records what
+``Encoder.encode`` / ``Encoder.forward`` (``model.py:59-86``) return on the PyTorch-CPU
+path.  Fixtures are DATA only: case parameters, code indices, argmin margins, SHA-256
+of the bit patterns of each stage, a few full rows, float64 checksums.  Nothing of the
+reference's source travels; the GPU box rebuilds inputs and weights from the seed.
+
+Vocoder half: the reference's arithmetic (third-party ``rnnms``) is absent, so there is
+nothing to import; ``vocoder_selforacle.npz`` is produced by this project's own CPU
+oracle and is labelled self-oracle (parity unpinned).
+
+Usage:  python tools/gen_golden.py            (writes tests/golden/)
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vectorquantizedcpc_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# name -> (B, T, ln_affine, codebook)
+ENCODER_CASES = {
+    "c1_init": (1, 200, "init", "init"),          # BASELINE configs[0]: one 2 s utterance
+    "c2_init": (64, 128, "init", "init"),         # BASELINE configs[1]: 64 x 128 frames
+    "c2_random_data": (64, 128, "random", "data"),  # perturbed LN affine, data-scale codebook
+    "ragged_3x32": (3, 32, "random", "init"),     # 48 rows, smallest MKL "large-M" regime
+    "tiny_1x16": (1, 16, "init", "init"),         # 8 rows: reference takes MKL's small-M path
+}
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def import_reference():
+    for name in ("omegaconf", "omegaconf.omegaconf"):
+        m = types.ModuleType(name)
+        m.MISSING = "???"
+        sys.modules[name] = m
+    sys.path.insert(0, "/root/reference")
+    import model  # noqa
+    return model
+
+
+def encoder_fixture(model, name, B, T, ln_affine, codebook):
+    torch.manual_seed(0)
+    enc = model.Encoder(model.ConfEncoder(80, 512, 512, 64, 256))
+    sd = synth.encoder_state_dict(ln_affine=ln_affine, codebook=codebook)
+    assert list(sd.keys()) == list(enc.state_dict().keys())
+    enc.load_state_dict(sd)
+    enc.eval()
+    mel = synth.mel(name, B, T)
+    stages = {}
+    enc.conv.register_forward_hook(lambda m, i, o: stages.__setitem__("conv", o.transpose(1, 2).contiguous().clone()))
+    for i, mod in enumerate(enc.encoder):
+        if not isinstance(mod, torch.nn.ReLU):       # ReLU is in-place: its input hook output is overwritten
+            mod.register_forward_hook(lambda m, inp, o, i=i: stages.__setitem__(f"enc{i}", o.clone()))
+    with torch.no_grad():
+        z, c, idx = enc.encode(mel)
+        z_pre = stages["enc14"]
+        # argmin margins from the reference's own distance matrix (model.py:107-110)
+        E = enc.codebook.embedding
+        xf = z_pre.reshape(-1, 64)
+        dist = torch.addmm(torch.sum(E ** 2, dim=1) + torch.sum(xf ** 2, dim=1, keepdim=True),
+                           xf, E.t(), alpha=-2.0, beta=1.0)
+        top2 = torch.topk(dist, 2, dim=1, largest=False).values
+        zf, cf, loss, ppl = enc(mel)
+    out = {
+        "case": np.array([B, T]), "ln_affine": np.array(ln_affine), "codebook": np.array(codebook),
+        "indices": idx.numpy().astype(np.int16),
+        "d_best": top2[:, 0].numpy(), "d_second": top2[:, 1].numpy(),
+        "n_exact_ties": np.array(int((top2[:, 0] == top2[:, 1]).sum())),
+        "loss": np.array(loss.item(), np.float32), "perplexity": np.array(ppl.item(), np.float32),
+    }
+    named = {"conv": stages["conv"], "z_pre": z_pre, "z": z, "c": c, "z_fwd": zf, "c_fwd": cf}
+    for i in (0, 2, 3, 5, 6, 8, 9, 11, 12):
+        named[f"enc{i}"] = stages[f"enc{i}"]
+    for k, v in named.items():
+        a = v.detach().numpy()
+        a2 = a.reshape(-1, a.shape[-1])
+        out[f"sha_{k}"] = np.array(sha(a))
+        out[f"sum_{k}"] = np.array([a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum()])
+        out[f"rows_{k}"] = a2[:: max(1, a2.shape[0] // 4)][:4].copy()   # 4 spread-out full rows
+    np.savez_compressed(os.path.join(GOLD, f"encoder_{name}.npz"), **out)
+    ulp = np.spacing(np.abs(out["d_best"]).astype(np.float32))
+    print(f"{name}: rows={B * T // 2} exact ties={out['n_exact_ties']} "
+          f"rows with margin<=4ulp={(out['d_second'] - out['d_best'] <= 4 * ulp).sum()} "
+          f"loss={out['loss']:.6g} ppl={out['perplexity']:.6g}")
+
+
+def glue_fixture():
+    """network_vocoder.py:69-77 glue layout, restated with torch ops on CPU and frozen as data.
+
+    (The reference module itself needs ``rnnms`` to import; SURVEY 8c verified this layout
+    against the reference with a capture stub.  Parity of the recurrence stays unpinned.)
+    """
+    sd = synth.vocoder_state_dict()
+    z = synth.randint("glue/z", (2, 5), 512)
+    spk = synth.randint("glue/spk", (2,), 102)
+    ze = torch.nn.functional.embedding(z, sd["code_embedding.weight"])
+    zu = torch.nn.functional.interpolate(ze.transpose(1, 2), scale_factor=2).transpose(1, 2)
+    se = torch.nn.functional.embedding(spk, sd["speaker_embedding.weight"])
+    series = torch.cat((zu, se.unsqueeze(1).expand(-1, zu.size(1), -1)), dim=-1)
+    np.savez_compressed(os.path.join(GOLD, "vocoder_glue.npz"), z=z.numpy(), speaker=spk.numpy(),
+                        series=series.numpy())
+
+
+def vocoder_selforacle():
+    import oracle
+    sd = synth.vocoder_state_dict()
+    out = {}
+    for u, (tc, steps) in enumerate(((3, 960), (2, 640))):
+        z = synth.randint(f"voc/z{u}", (tc,), 512).numpy()
+        spk = int(synth.randint(f"voc/spk{u}", (1,), 102)[0])
+        r = oracle.vocoder_generate(sd, z, spk, seed=synth.SEED, utterance=u, n_steps=steps, want_logits=True)
+        out[f"z{u}"], out[f"spk{u}"] = z, np.array(spk)
+        out[f"samples{u}"] = r["samples"].astype(np.int16)
+        out[f"wav{u}"] = r["wav"]
+        out[f"logits{u}"] = r["logits"][::64].copy()       # every 64th step
+        out[f"cond{u}"] = oracle.vocoder_condition(sd, z, spk)
+    np.savez_compressed(os.path.join(GOLD, "vocoder_selforacle.npz"), **out)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    model = import_reference()
+    print("reference imported from", model.__file__, "| torch", torch.__version__,
+          "| cpu capability", torch.backends.cpu.get_cpu_capability(), "| threads", torch.get_num_threads())
+    for name, args in ENCODER_CASES.items():
+        encoder_fixture(model, name, *args)
+    glue_fixture()
+    vocoder_selforacle()
+    print("wrote", sorted(os.listdir(GOLD)))
+
+
+if __name__ == "__main__":
+    main()
