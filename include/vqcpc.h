@@ -1,0 +1,180 @@
+/*
+ * vqcpc.h -- C ABI of libvqcpc_hip.so: the MI355X (gfx950) implementation of the
+ * VQ-CPC inference hot path.
+ *
+ * The reference (tarepan/VectorQuantizedCPC) has no FFI for this path; its seam is the
+ * nn.Module method surface.  Each entry point below names the reference interface it
+ * replaces (file:line in /root/reference).  The Python drop-in classes in
+ * vectorquantizedcpc_amd/{model,network_vocoder}.py bind these with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - Every pointer marked DEVICE is fp32 / int64 memory on the current HIP device,
+ *    contiguous, borrowed for the duration of the enqueued work.  HOST pointers are read
+ *    before the call returns.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream).  No call synchronises the device except where stated.
+ *  - Return 0 on success, a negative vqcpc_status otherwise; never throws.
+ *    vqcpc_last_error() returns a thread-local message for the last failure.
+ *  - One handle per device; a handle is not thread-safe; distinct handles are independent.
+ *  - No CPU fallback exists: without a gfx950 device every compute call fails.
+ */
+#ifndef VQCPC_H
+#define VQCPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQCPC_ABI_VERSION 1
+
+typedef enum {
+    VQCPC_OK = 0,
+    VQCPC_ERR_INVALID = -1,     /* bad argument / unsupported shape        */
+    VQCPC_ERR_HIP = -2,         /* a HIP runtime call failed               */
+    VQCPC_ERR_NO_DEVICE = -3,   /* no gfx950 device visible                */
+    VQCPC_ERR_ALLOC = -4
+} vqcpc_status;
+
+int vqcpc_abi_version(void);
+const char *vqcpc_last_error(void);
+
+/* Number of visible HIP devices whose arch is gfx950 (0 = none; never faults). */
+int vqcpc_device_count(void);
+
+/* ------------------------------------------------------------------ Encoder ---------- */
+
+/* Encoder.state_dict() (model.py:43-57).  DEVICE pointers, shapes as in the reference:
+ * conv_weight (channels, in_channels, 4); ln_*[i] (channels) for encoder.{0,3,6,9,12};
+ * fc_weight[i] (channels, channels) for encoder.{2,5,8,11}; out_weight (z_dim, channels),
+ * out_bias (z_dim); codebook (n_embeddings, z_dim) = codebook.embedding;
+ * rnn_* = nn.LSTM(z_dim, c_dim) parameters (4*c_dim rows, gate order i,f,g,o).
+ * Supported: in_channels % 16 == 0 (<= 256), channels == 512, z_dim == 64,
+ * n_embeddings % 64 == 0 (<= 4096), c_dim % 64 == 0 (<= 1024). */
+typedef struct {
+    const float *conv_weight;
+    const float *ln_weight[5];
+    const float *ln_bias[5];
+    const float *fc_weight[4];
+    const float *out_weight;
+    const float *out_bias;
+    const float *codebook;
+    const float *rnn_w_ih, *rnn_w_hh, *rnn_b_ih, *rnn_b_hh;
+    int in_channels, channels, n_embeddings, z_dim, c_dim;
+} vqcpc_encoder_weights;
+
+typedef struct vqcpc_encoder vqcpc_encoder;
+
+/* Replaces Encoder.__init__ + load_state_dict (model.py:33-57; encode.py:24-30).
+ * Copies and re-lays the weights on the current device (synchronises once). */
+int vqcpc_encoder_create(const vqcpc_encoder_weights *w, vqcpc_encoder **out);
+void vqcpc_encoder_destroy(vqcpc_encoder *enc);
+
+/* conv_mode: which of the reference's two CPU conv back-ends to reproduce bit for bit
+ * (ATen chooses by call shape; they sum in different orders):
+ *   0 = as the reference would for this (B, T): 2 if B > 1 or B*in_channels*T > 20480 else 1
+ *   1 = im2col + sgemm order (a single short utterance, encode.py:44-46's batch-1 call)
+ *   2 = oneDNN direct-conv order (batched calls, e.g. vocoder.py:59) */
+#define VQCPC_CONV_AUTO 0
+#define VQCPC_CONV_IM2COL 1
+#define VQCPC_CONV_DIRECT 2
+
+/* Replaces Encoder.encode (model.py:59-70; callers encode.py:46, convert.py:76,
+ * vocoder.py:59).  mel DEVICE (B, in_channels, T), T even.  Outputs DEVICE:
+ * z_q (B, T/2, z_dim) quantised vectors; idx (B, T/2) int64 code indices;
+ * c (B, T/2, c_dim) LSTM context or NULL to skip the LSTM (convert.py:76 discards it);
+ * z_pre (B, T/2, z_dim) pre-VQ activations (the encode.py:34-40 hook) or NULL.
+ * Code indices are bit-identical to the reference's PyTorch-CPU path for calls with
+ * >= 16 output frames ("Bit-exactness contract"). */
+int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
+                         float *z_q, float *c, int64_t *idx, float *z_pre, void *stream);
+
+/* Activations after one stage of the front end for the same inputs as encode() -- the analogue
+ * of a forward hook on the reference's modules (encode.py:34-40 hooks encoder.encoder[-1]):
+ * stage 0 = conv output transposed to rows (model.py:65-67), 1 = encoder.0+1 (LN, ReLU),
+ * 2+2l = encoder.{2,5,8,11}[l] (Linear), 3+2l = the LN+ReLU after it, 10 = encoder.14 (z_pre).
+ * out DEVICE (B*T/2, channels) fp32, or (B*T/2, z_dim) for stage 10. */
+int vqcpc_encoder_stage(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
+                        int stage, float *out, void *stream);
+
+/* Replaces the eval branch of VQEmbeddingEMA.forward as used by Encoder.forward
+ * (model.py:72-86, :117-155): from encode()'s z_pre / z_q / idx (n_rows = B*T/2) computes
+ * z_st = x + (q - x) (DEVICE, n_rows*z_dim, or NULL), loss = 0.25*mse (DEVICE scalar) and
+ * perplexity (DEVICE scalar).  The context for forward() is the LSTM over z_st:
+ * vqcpc_encoder_context. */
+int vqcpc_encoder_forward_stats(vqcpc_encoder *enc, const float *z_pre, const float *z_q,
+                                const int64_t *idx, int n_rows, float *z_st, float *loss,
+                                float *perplexity, void *stream);
+
+/* nn.LSTM over z (B, Tz, z_dim) -> c (B, Tz, c_dim)  (model.py:69 / :85). */
+int vqcpc_encoder_context(vqcpc_encoder *enc, const float *z, int B, int Tz, float *c,
+                          void *stream);
+
+/* ------------------------------------------------------------------ Vocoder ---------- */
+
+/* Vocoder.state_dict(): own tables (network_vocoder.py:37-38) plus the RNN_MS core the
+ * reference imports from the third-party `rnnms` package (network_vocoder.py:8, :39;
+ * shapes from config.py:58-77, :198-199).  DEVICE pointers.
+ * prenet: 2-layer bidirectional nn.GRU(dz+ds -> Hp), index [layer][direction];
+ * ar: embedding (n_cls, de); nn.GRU(de + 2*Hp -> Hr) single layer, gate order r,z,n;
+ * fc1 (Hf, Hr) + ReLU; fc2 (n_cls, Hf).
+ * Supported: dz + ds and 2*Hp multiples of 16; Hp % 4 == 0; Hr % 16 == 0, Hr % 4 == 0;
+ * Hf % 16 == 0; n_cls == 256 (bits == 8); de % 4 == 0. */
+typedef struct {
+    const float *code_embedding;      /* (n_codes, dz)           */
+    const float *speaker_embedding;   /* (n_speakers, ds)        */
+    const float *prenet_w_ih[2][2], *prenet_w_hh[2][2], *prenet_b_ih[2][2], *prenet_b_hh[2][2];
+    const float *ar_embedding;        /* (n_cls, de)             */
+    const float *ar_w_ih, *ar_w_hh, *ar_b_ih, *ar_b_hh;   /* (3Hr, de+2Hp), (3Hr, Hr), (3Hr) x2 */
+    const float *fc1_weight, *fc1_bias, *fc2_weight, *fc2_bias;
+    int n_codes, dz, n_speakers, ds, Hp, de, Hr, Hf, n_cls;
+    int upsample_t;                   /* samples per conditioning frame (config.py:70 = hop 160) */
+    int bits_mu_law;                  /* config.py:69 */
+} vqcpc_vocoder_weights;
+
+typedef struct vqcpc_vocoder vqcpc_vocoder;
+
+/* Replaces Vocoder.__init__ + load_state_dict (network_vocoder.py:31-39; convert.py:33,45). */
+int vqcpc_vocoder_create(const vqcpc_vocoder_weights *w, vqcpc_vocoder **out);
+void vqcpc_vocoder_destroy(vqcpc_vocoder *voc);
+
+/* Replaces Vocoder.generate (network_vocoder.py:69-78; callers convert.py:77,
+ * vocoder.py:74-76).  idx DEVICE (B, Tc) int64 code indices; speaker DEVICE (B) int64;
+ * n_codes HOST (B) per-utterance valid code counts, or NULL = all Tc (ragged batches:
+ * utterance b produces 2*upsample_t*n_codes[b] samples, the rest of its row is zero).
+ * Sampling protocol (project spec; the reference draws from torch's global CPU RNG, which
+ * no device kernel can share): sample t of utterance u uses the uniform
+ * Philox4x32-10(counter=(t, utt_base+b, 0, 0), key=seed) word0 >> 8 * 2^-24 and the
+ * inverse CDF of softmax(logits).  Outputs DEVICE: wav (B, L) fp32 in [-1, 1] with
+ * L = 2*upsample_t*Tc, mu-law decoded (preprocess.py:30-35); mulaw (B, L) int64 class
+ * indices or NULL.  max_steps > 0 stops after that many samples (tests). */
+int vqcpc_vocoder_generate(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
+                           int B, int Tc, const int *n_codes, uint64_t seed, uint32_t utt_base,
+                           float *wav, int64_t *mulaw, int max_steps, void *stream);
+
+/* Replaces Vocoder.forward (network_vocoder.py:41-67; caller vocoder.py:62): teacher-forced
+ * energies.  x DEVICE (B, Ts) int64 mu-law input samples, Ts <= 2*upsample_t*Tc;
+ * logits DEVICE (B, Ts, n_cls) fp32. */
+int vqcpc_vocoder_logits(vqcpc_vocoder *voc, const int64_t *x, const int64_t *idx,
+                         const int64_t *speaker, int B, int Tc, int Ts, float *logits,
+                         void *stream);
+
+/* Conditioning series after the prenet, (B, 2*Tc, 2*Hp) DEVICE -- stage-level tests. */
+int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
+                            int B, int Tc, float *cond, void *stream);
+
+/* Decode-loop options.  use_graph: replay the per-sample kernels from a captured hipGraph
+ * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay. */
+int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
+
+/* Device time, in milliseconds, of the decode loop's dominant kernel (the GRU step) over
+ * the last generate() call, measured with HIP events on the launch stream, and the number
+ * of launches it covers.  Valid after the stream has been synchronised. */
+int vqcpc_vocoder_last_timing(vqcpc_vocoder *voc, float *loop_ms, int *n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQCPC_H */

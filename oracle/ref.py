@@ -253,9 +253,11 @@ def vocoder_condition(sd, z, speaker, upsample=160):
     return out
 
 
-def vocoder_generate(sd, z, speaker, seed, utterance=0, n_steps=None, forced=None,
+def vocoder_generate(sd, z, speaker, seed, utterance=0, n_steps=None, inputs=None,
                      want_logits=False, upsample=160, bits=8):
-    """Vocoder.generate for ONE utterance (project spec) -> dict(samples, wav, logits)."""
+    """Vocoder.generate for ONE utterance (project spec) -> dict(samples, wav, logits).
+
+    ``inputs``: teacher forcing -- the previous-sample fed at step t (Vocoder.forward semantics)."""
     z = _i64(z)
     w, keep = _voc_struct(sd, upsample, bits)
     total = upsample * 2 * z.size
@@ -263,12 +265,12 @@ def vocoder_generate(sd, z, speaker, seed, utterance=0, n_steps=None, forced=Non
     samples = np.empty(n_steps, np.int64)
     wav = np.empty(n_steps, np.float32)
     logits = np.empty((n_steps, w.n_cls), np.float32) if want_logits else None
-    forced = None if forced is None else _i64(forced)
-    if forced is not None:
-        assert forced.size >= n_steps
+    inputs = None if inputs is None else _i64(inputs)
+    if inputs is not None:
+        assert inputs.size >= n_steps
     rc = lib().orc_vocoder_generate(C.byref(w), _p(z), C.c_int64(int(speaker)), z.size,
                                     C.c_uint64(int(seed)), C.c_uint32(int(utterance)), n_steps,
-                                    _p(forced), _p(samples), _p(wav), _p(logits))
+                                    _p(inputs), _p(samples), _p(wav), _p(logits))
     assert rc == 0
     del keep
     return {"samples": samples, "wav": wav, "logits": logits}

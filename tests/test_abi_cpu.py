@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/vqcpc.h declares, the Python mirror keeps the reference's surface, and the product
+path fails loudly without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import vectorquantizedcpc_amd as V
+from vectorquantizedcpc_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vqcpc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqcpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vqcpc.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names
+    assert _lib.load().vqcpc_abi_version() == 1
+
+
+def test_state_dict_surface_matches_reference():
+    enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
+    sd = synth.encoder_state_dict()
+    assert list(enc.state_dict().keys()) == list(sd.keys())        # SURVEY 8a-1 key set and order
+    assert all(enc.state_dict()[k].shape == sd[k].shape for k in sd)
+    enc.load_state_dict(sd)
+    voc = V.Vocoder(V.ConfVocoder())
+    sv = synth.vocoder_state_dict()
+    assert set(voc.state_dict().keys()) == set(sv.keys())
+    assert all(voc.state_dict()[k].shape == sv[k].shape for k in sv)
+    voc.load_state_dict(sv)
+    assert isinstance(enc.encoder[-1], torch.nn.Linear)             # encode.py:40 hooks this module
+
+
+def test_no_cpu_fallback():
+    enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256)).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc.encode(torch.zeros(1, 80, 32))
+    voc = V.Vocoder(V.ConfVocoder()).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        voc.generate(torch.zeros(1, 4, dtype=torch.long), torch.zeros(1, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may import or load it."""
+    pkg = os.path.join(ROOT, "vectorquantizedcpc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "libvqcpc_oracle" not in text, f
+            if f.endswith((".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "#include \"../../oracle" not in text and "dlopen" not in text, f
+
+
+def test_synth_is_deterministic():
+    a = synth.encoder_state_dict()["encoder.2.weight"]
+    b = synth.encoder_state_dict()["encoder.2.weight"]
+    assert torch.equal(a, b)
+    assert abs(float(synth.mel("x", 2, 8).mean()) - 0.5) < 0.05

@@ -1,0 +1,566 @@
+// encoder.hip -- Encoder.encode / Encoder.forward on gfx950 (reference: model.py:43-155).
+//
+// Every kernel here reproduces the rounding sequence of the reference's PyTorch-CPU path
+// (oracle/vqcpc_oracle.c documents each order and tests pin it against the reference):
+//   * contractions are fp32 MFMA chains (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain),
+//     restarted at the K-block boundaries the reference's MKL / oneDNN kernels use;
+//   * LayerNorm moments follow ATen's 8-lane Welford cascade;
+//   * |x|^2 follows ATen's cascade_sum order; the VQ distance is one fma per (row, code).
+// Build with -ffp-contract=off: every fused multiply-add below is written explicitly.
+#include "common.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing + device query
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vq_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *vqcpc_last_error(void) { return g_err; }
+extern "C" int vqcpc_abi_version(void) { return VQCPC_ABI_VERSION; }
+extern "C" int vqcpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+static int require_gfx950() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        vq_set_error("no HIP device: libvqcpc_hip has no CPU fallback");
+        return VQCPC_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        vq_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", dev, p.gcnArchName);
+        return VQCPC_ERR_NO_DEVICE;
+    }
+    return VQCPC_OK;
+}
+int vq_require_gfx950() { return require_gfx950(); }
+
+// ------------------------------------------------------------------------------------------
+// Exact-chain GEMM: 64x64 output tile per 256-thread workgroup, 4 waves as 2x2 of 32x32,
+// one v_mfma_f32_32x32x2_f32 per two k.  LDS tiles are k-major ([k][row], stride 65) so the
+// MFMA operand reads are conflict-free row-contiguous b32 reads.
+// ------------------------------------------------------------------------------------------
+#define GT_BM 64
+#define GT_BN 64
+#define GT_BK 32
+#define GT_LD 65
+
+struct GemmP {
+    const float *A; int lda;
+    const float *W;            // (N, K) row-major
+    const float *bias;         // (N) or null
+    float *Y; int ldy;
+    int M, N, K, KC;
+    // im2col source (AMODE 1/2): mel (B, C, T)
+    const float *x; int C, T, To;
+    // VQ epilogue (EPI 1)
+    const float *e2, *x2; float *pd; int *pi; int npart;
+};
+
+template <int AMODE>
+__device__ __forceinline__ void load_a_tile(const GemmP &p, float (*As)[GT_LD], int m0, int k0, int tid) {
+    const int row = tid >> 2, kq = (tid & 3) * 8;
+    const int m = m0 + row;
+    float v[8];
+    if (AMODE == 0) {
+        if (m < p.M) {
+            const float4 *src = (const float4 *)(p.A + (size_t)m * p.lda + k0 + kq);
+            float4 a = src[0], b = src[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+    } else {
+        int b = 0, tt = 0;
+        if (m < p.M) { b = m / p.To; tt = m - b * p.To; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kidx = k0 + kq + i;
+            int c, tap;
+            if (AMODE == 1) { c = kidx >> 2; tap = kidx & 3; }
+            else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
+            const int ti = 2 * tt + tap - 1;
+            v[i] = (m < p.M && ti >= 0 && ti < p.T) ? p.x[((size_t)b * p.C + c) * p.T + ti] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) As[kq + i][row] = v[i];
+}
+
+__device__ __forceinline__ void load_w_tile(const GemmP &p, float (*Ws)[GT_LD], int n0, int k0, int tid) {
+    const int row = tid >> 2, kq = (tid & 3) * 8;
+    const float4 *src = (const float4 *)(p.W + (size_t)(n0 + row) * p.K + k0 + kq);
+    float4 a = src[0], b = src[1];
+    Ws[kq + 0][row] = a.x; Ws[kq + 1][row] = a.y; Ws[kq + 2][row] = a.z; Ws[kq + 3][row] = a.w;
+    Ws[kq + 4][row] = b.x; Ws[kq + 5][row] = b.y; Ws[kq + 6][row] = b.z; Ws[kq + 7][row] = b.w;
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_chain_kernel(GemmP p) {
+    __shared__ float As[GT_BK][GT_LD];
+    __shared__ float Ws[GT_BK][GT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, li = lane & 31;
+    const int n0 = blockIdx.x * GT_BN, m0 = blockIdx.y * GT_BM;
+    const int col = n0 + wn * 32 + li;
+
+    f32x16 acc, tot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; tot[r] = 0.f; }
+    bool first = true;
+
+    for (int k0 = 0; k0 < p.K; k0 += GT_BK) {
+        __syncthreads();
+        load_a_tile<AMODE>(p, As, m0, k0, tid);
+        load_w_tile(p, Ws, n0, k0, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GT_BK / 2; ++kk) {
+            const float a = As[2 * kk + half][wm * 32 + li];
+            const float b = Ws[2 * kk + half][wn * 32 + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if ((k0 + GT_BK) % p.KC == 0 || k0 + GT_BK >= p.K) {       // end of a K block: fold the chain
+            if (first) {
+                const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[r] = p.bias ? bv + acc[r] : acc[r];
+                first = false;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[r] = tot[r] + acc[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+    }
+
+    if (EPI == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.M) p.Y[(size_t)m * p.ldy + col] = tot[r];
+        }
+    } else {
+        // VQ distance + per-32-code partial argmin (model.py:107-112).
+        const float e2 = p.e2[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float x2 = p.x2[m < p.M ? m : p.M - 1];
+            float d = __builtin_fmaf(-2.0f, tot[r], e2 + x2);
+            int j = col;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const float od = __shfl_xor(d, off);
+                const int oj = __shfl_xor(j, off);
+                if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+            }
+            if (li == 0 && m < p.M) {
+                const int part = blockIdx.x * 2 + wn;
+                p.pd[(size_t)m * p.npart + part] = d;
+                p.pi[(size_t)m * p.npart + part] = j;
+            }
+        }
+    }
+}
+
+template <int AMODE, int EPI>
+static int launch_gemm(const GemmP &p, hipStream_t s) {
+    VQ_REQUIRE(p.N % GT_BN == 0 && p.K % GT_BK == 0 && p.KC % GT_BK == 0 && p.M > 0,
+               "gemm_chain: unsupported shape M=%d N=%d K=%d KC=%d", p.M, p.N, p.K, p.KC);
+    dim3 grid(p.N / GT_BN, (p.M + GT_BM - 1) / GT_BM);
+    hipLaunchKernelGGL((gemm_chain_kernel<AMODE, EPI>), grid, dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+int vq_gemm_chain(const float *A, int lda, const float *W, const float *bias, float *Y, int ldy,
+                  int M, int N, int K, int KC, hipStream_t s) {
+    VQ_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+               "gemm_chain: operands must be 16-byte aligned");
+    GemmP p{};
+    p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.Y = Y; p.ldy = ldy;
+    p.M = M; p.N = N; p.K = K; p.KC = KC;
+    return launch_gemm<0, 0>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm(512) + optional ReLU, ATen CPU order (see oracle orc_ln_moments).
+// One half-wave (32 lanes) per row: lane = chunk*8 + l runs the Welford chain of vector lane
+// l over chunk `chunk` (16 vectors of 8), merges by shuffles, then all lanes normalise.
+// ------------------------------------------------------------------------------------------
+struct LnConst { float inv[16]; float sc[8]; };
+
+__global__ __launch_bounds__(256) void ln512_kernel(const float *__restrict__ X, const float *__restrict__ g,
+                                                    const float *__restrict__ b, float *__restrict__ Y, int M,
+                                                    float eps, int relu, LnConst k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, ll = lane & 31;
+    const int row = (blockIdx.x * 4 + wave) * 2 + half;
+    const int rr = row < M ? row : M - 1;
+    const float *x = X + (size_t)rr * 512;
+    const int chunk = ll >> 3, l = ll & 7;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float xv = x[(chunk * 16 + j) * 8 + l];
+        const float d = xv - m1;
+        m1 = __builtin_fmaf(d, k.inv[j], m1);
+        m2 = __builtin_fmaf(d, xv - m1, m2);
+    }
+    // chunk 1 -> chunk 0, chunk 3 -> chunk 2   (AddMomentsVec, 16 + 16 vectors, c = 1/2)
+    float a1 = __shfl_down(m1, 8), a2 = __shfl_down(m2, 8);
+    {
+        const float delta = a1 - m1;
+        const float n1 = __builtin_fmaf(0.5f, delta, m1);
+        m2 = __builtin_fmaf((0.5f * 16.0f) * delta, delta, m2 + a2);
+        m1 = n1;
+    }
+    // (chunks 2,3) -> (chunks 0,1)              (32 + 32 vectors)
+    a1 = __shfl_down(m1, 16); a2 = __shfl_down(m2, 16);
+    {
+        const float delta = a1 - m1;
+        const float n1 = __builtin_fmaf(0.5f, delta, m1);
+        m2 = __builtin_fmaf((0.5f * 32.0f) * delta, delta, m2 + a2);
+        m1 = n1;
+    }
+    // the 8 vector lanes, serially (AddMoments, scalar)
+    float M1 = 0.f, M2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float s1 = __shfl(m1, half * 32 + q), s2 = __shfl(m2, half * 32 + q);
+        const float delta = s1 - M1;
+        M1 = __builtin_fmaf(k.sc[q], delta, M1);
+        M2 = M2 + __builtin_fmaf((delta * delta) * k.sc[q], (float)(64 * q), s2);
+    }
+    const float mean = M1, var = M2 / 512.0f;
+    // 1 / sqrt(var + eps), both correctly rounded in fp32 (via fp64: innocuous double rounding)
+    const float sd = (float)sqrt((double)(var + eps));
+    const float rstd = (float)(1.0 / (double)sd);
+    if (row < M) {
+        float *y = Y + (size_t)row * 512;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = q * 128 + ll * 4;
+            const float4 xv = *(const float4 *)(x + e);
+            const float4 gv = *(const float4 *)(g + e);
+            const float4 bv = *(const float4 *)(b + e);
+            float4 o;
+            o.x = __builtin_fmaf((xv.x - mean) * rstd, gv.x, bv.x);
+            o.y = __builtin_fmaf((xv.y - mean) * rstd, gv.y, bv.y);
+            o.z = __builtin_fmaf((xv.z - mean) * rstd, gv.z, bv.z);
+            o.w = __builtin_fmaf((xv.w - mean) * rstd, gv.w, bv.w);
+            if (relu) {
+                o.x = o.x < 0.f ? 0.f : o.x; o.y = o.y < 0.f ? 0.f : o.y;
+                o.z = o.z < 0.f ? 0.f : o.z; o.w = o.w < 0.f ? 0.f : o.w;
+            }
+            *(float4 *)(y + e) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// torch.sum(v**2, dim=1) over 64 floats, ATen cascade order (oracle orc_sumsq64).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sumsq64(const float *v) {
+    float sq[64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 t = *(const float4 *)(v + 4 * i);
+        sq[4 * i + 0] = t.x * t.x; sq[4 * i + 1] = t.y * t.y; sq[4 * i + 2] = t.z * t.z; sq[4 * i + 3] = t.w * t.w;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float q0 = sq[l] + sq[32 + l], q1 = sq[8 + l] + sq[40 + l];
+        const float q2 = sq[16 + l] + sq[48 + l], q3 = sq[24 + l] + sq[56 + l];
+        acc += ((q0 + q1) + q2) + q3;
+    }
+    return acc;
+}
+__global__ void rowsumsq64_kernel(const float *__restrict__ X, float *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sumsq64(X + (size_t)i * 64);
+}
+
+// First-index argmin over the per-32-code partials + F.embedding gather (model.py:112-115).
+__global__ void vq_finalize_kernel(const float *__restrict__ pd, const int *__restrict__ pi, int npart,
+                                   const float *__restrict__ E, int64_t *__restrict__ idx,
+                                   float *__restrict__ zq, int n) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float best = pd[(size_t)row * npart];
+    int bj = pi[(size_t)row * npart];
+    for (int q = 1; q < npart; ++q) {
+        const float d = pd[(size_t)row * npart + q];
+        if (d < best) { best = d; bj = pi[(size_t)row * npart + q]; }
+    }
+    if (lane == 0) idx[row] = bj;
+    zq[(size_t)row * 64 + lane] = E[(size_t)bj * 64 + lane];
+}
+
+// Eval-branch statistics of VQEmbeddingEMA.forward (model.py:147-153): deterministic two-level
+// reductions (per-block partials, then one block in fixed order).
+__global__ __launch_bounds__(256) void vq_stats_partial_kernel(const float *__restrict__ x, const float *__restrict__ q,
+                                                               const int64_t *__restrict__ idx, int n_rows,
+                                                               float *__restrict__ zst, double *__restrict__ part_se,
+                                                               unsigned *__restrict__ hist) {
+    __shared__ double red[256];
+    const size_t n = (size_t)n_rows * 64;
+    double se = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float xv = x[i], qv = q[i];
+        const float d = xv - qv;
+        se += (double)d * (double)d;
+        if (zst) zst[i] = xv + (qv - xv);
+    }
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n_rows; r += gridDim.x * 256) atomicAdd(&hist[idx[r]], 1u);
+    red[threadIdx.x] = se;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part_se[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void vq_stats_final_kernel(const double *__restrict__ part_se, int nparts,
+                                                             const unsigned *__restrict__ hist, int n_emb, int n_rows,
+                                                             float *__restrict__ loss, float *__restrict__ ppl) {
+    __shared__ double red[256];
+    double ent = 0.0;
+    for (int j = threadIdx.x; j < n_emb; j += 256) {
+        const float p = (float)((double)hist[j] / (double)n_rows);
+        ent += (double)(p * logf(p + 1e-10f));
+    }
+    red[threadIdx.x] = ent;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double se = 0.0;
+        for (int i = 0; i < nparts; ++i) se += part_se[i];
+        *loss = (float)(0.25 * se / ((double)n_rows * 64.0));
+        *ppl = expf((float)-red[0]);
+    }
+}
+
+// conv.weight (O, C, 4) -> GEMM operand (O, 4C) in the k order of each reference back-end.
+__global__ void conv_weight_permute_kernel(const float *__restrict__ w, float *__restrict__ w1,
+                                           float *__restrict__ w2, int O, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = 4 * C;
+    if (i >= O * K) return;
+    const int o = i / K, kidx = i - o * K;
+    w1[i] = w[i];                                          // mode 1: kidx = c*4 + tap (native layout)
+    const int rem = kidx & 63, tap = rem >> 4, c = (kidx >> 6) * 16 + (rem & 15);
+    w2[i] = w[((size_t)o * C + c) * 4 + tap];              // mode 2: [block of 16 c][tap][c in block]
+}
+
+// ------------------------------------------------------------------------------------------
+// handle + ABI
+// ------------------------------------------------------------------------------------------
+struct vqcpc_encoder {
+    int in_channels, channels, n_emb, z_dim, c_dim;
+    float *conv_w1 = nullptr, *conv_w2 = nullptr;
+    float *ln_g[5] = {}, *ln_b[5] = {};
+    float *fc_w[4] = {};
+    float *out_w = nullptr, *out_b = nullptr;
+    float *codebook = nullptr, *e2 = nullptr;
+    LstmPlan *lstm = nullptr;
+    LnConst lnc;
+    DevBuf bufA, bufB, x2, pd, pi, zpre, stats;
+};
+
+static int dev_copy(float **dst, const float *src, size_t n) {
+    HIP_TRY(hipMalloc((void **)dst, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return VQCPC_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != VQCPC_OK) return rc_; } while (0)
+
+extern "C" void vqcpc_encoder_destroy(vqcpc_encoder *e) {
+    if (!e) return;
+    float *ptrs[] = {e->conv_w1, e->conv_w2, e->out_w, e->out_b, e->codebook, e->e2};
+    for (float *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 5; ++i) { if (e->ln_g[i]) (void)hipFree(e->ln_g[i]); if (e->ln_b[i]) (void)hipFree(e->ln_b[i]); }
+    for (int i = 0; i < 4; ++i) if (e->fc_w[i]) (void)hipFree(e->fc_w[i]);
+    if (e->lstm) vq_lstm_plan_destroy(e->lstm);
+    e->bufA.release(); e->bufB.release(); e->x2.release(); e->pd.release(); e->pi.release();
+    e->zpre.release(); e->stats.release();
+    delete e;
+}
+
+static int encoder_create_impl(const vqcpc_encoder_weights *w, vqcpc_encoder *e) {
+    const int C = w->in_channels, CH = w->channels;
+    e->in_channels = C; e->channels = CH; e->n_emb = w->n_embeddings; e->z_dim = w->z_dim; e->c_dim = w->c_dim;
+    for (int j = 0; j < 16; ++j) e->lnc.inv[j] = 1.0f / (float)(j + 1);
+    for (int q = 0; q < 8; ++q) e->lnc.sc[q] = (float)64 / (float)(64 * (q + 1));
+    const size_t nconv = (size_t)CH * C * 4;
+    HIP_TRY(hipMalloc((void **)&e->conv_w1, nconv * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&e->conv_w2, nconv * sizeof(float)));
+    hipLaunchKernelGGL(conv_weight_permute_kernel, dim3((unsigned)((nconv + 255) / 256)), dim3(256), 0, 0,
+                       w->conv_weight, e->conv_w1, e->conv_w2, CH, C);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < 5; ++i) { TRY(dev_copy(&e->ln_g[i], w->ln_weight[i], CH)); TRY(dev_copy(&e->ln_b[i], w->ln_bias[i], CH)); }
+    for (int i = 0; i < 4; ++i) TRY(dev_copy(&e->fc_w[i], w->fc_weight[i], (size_t)CH * CH));
+    TRY(dev_copy(&e->out_w, w->out_weight, (size_t)w->z_dim * CH));
+    TRY(dev_copy(&e->out_b, w->out_bias, w->z_dim));
+    TRY(dev_copy(&e->codebook, w->codebook, (size_t)w->n_embeddings * w->z_dim));
+    HIP_TRY(hipMalloc((void **)&e->e2, w->n_embeddings * sizeof(float)));
+    hipLaunchKernelGGL(rowsumsq64_kernel, dim3((w->n_embeddings + 63) / 64), dim3(64), 0, 0, e->codebook, e->e2,
+                       w->n_embeddings);
+    HIP_TRY(hipGetLastError());
+    TRY(vq_lstm_plan_create(w->rnn_w_ih, w->rnn_w_hh, w->rnn_b_ih, w->rnn_b_hh, w->z_dim, w->c_dim, &e->lstm));
+    HIP_TRY(hipDeviceSynchronize());
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_encoder_create(const vqcpc_encoder_weights *w, vqcpc_encoder **out) {
+    VQ_REQUIRE(w && out, "vqcpc_encoder_create: null argument");
+    *out = nullptr;
+    TRY(require_gfx950());
+    VQ_REQUIRE(w->channels == 512 && w->z_dim == 64, "encoder: channels must be 512 and z_dim 64 (got %d, %d)",
+               w->channels, w->z_dim);
+    VQ_REQUIRE(w->in_channels % 16 == 0 && w->in_channels > 0 && w->in_channels <= 256,
+               "encoder: in_channels must be a multiple of 16 in (0, 256] (got %d)", w->in_channels);
+    VQ_REQUIRE(w->n_embeddings % 64 == 0 && w->n_embeddings > 0 && w->n_embeddings <= 4096,
+               "encoder: n_embeddings must be a multiple of 64 in (0, 4096] (got %d)", w->n_embeddings);
+    VQ_REQUIRE(w->c_dim % 64 == 0 && w->c_dim > 0 && w->c_dim <= 1024, "encoder: c_dim must be a multiple of 64 (got %d)", w->c_dim);
+    vqcpc_encoder *e = new vqcpc_encoder();
+    int rc = encoder_create_impl(w, e);
+    if (rc != VQCPC_OK) { vqcpc_encoder_destroy(e); return rc; }
+    *out = e;
+    return VQCPC_OK;
+}
+
+// conv + seg-FC stack up to `stop_stage` (0 conv, 1 LN0+ReLU, 2+2l FC_l, 3+2l LN_l+ReLU, 10 z_pre).
+// Returns the device buffer holding that stage's rows in *stage_out.
+static int encoder_front(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode, int stop_stage,
+                         float *zp, const float **stage_out, hipStream_t s) {
+    const int C = e->in_channels, CH = e->channels, To = T / 2, N = B * To;
+    if (conv_mode == VQCPC_CONV_AUTO)
+        conv_mode = (B > 1 || (long)B * C * T > 20480) ? VQCPC_CONV_DIRECT : VQCPC_CONV_IM2COL;
+    TRY(e->bufA.reserve((size_t)N * CH * sizeof(float)));
+    TRY(e->bufB.reserve((size_t)N * CH * sizeof(float)));
+    float *a = e->bufA.as<float>(), *b = e->bufB.as<float>();
+
+    // conv (model.py:65) as an im2col GEMM in the reference back-end's summation order
+    GemmP p{};
+    p.W = conv_mode == VQCPC_CONV_IM2COL ? e->conv_w1 : e->conv_w2;
+    p.Y = a; p.ldy = CH; p.M = N; p.N = CH; p.K = 4 * C;
+    p.KC = conv_mode == VQCPC_CONV_IM2COL ? 4 * C : 64;
+    p.x = mel; p.C = C; p.T = T; p.To = To;
+    if (conv_mode == VQCPC_CONV_IM2COL) TRY((launch_gemm<1, 0>(p, s)));
+    else TRY((launch_gemm<2, 0>(p, s)));
+    *stage_out = a;
+    if (stop_stage == 0) return VQCPC_OK;
+
+    // seg-FC stack (model.py:46-55, :67)
+    const dim3 lng((N + 7) / 8), lnb(256);
+    hipLaunchKernelGGL(ln512_kernel, lng, lnb, 0, s, a, e->ln_g[0], e->ln_b[0], b, N, 1e-5f, 1, e->lnc);
+    *stage_out = b;
+    if (stop_stage == 1) return VQCPC_OK;
+    for (int l = 0; l < 4; ++l) {
+        TRY(vq_gemm_chain(b, CH, e->fc_w[l], nullptr, a, CH, N, CH, CH, 256, s));
+        *stage_out = a;
+        if (stop_stage == 2 + 2 * l) return VQCPC_OK;
+        hipLaunchKernelGGL(ln512_kernel, lng, lnb, 0, s, a, e->ln_g[l + 1], e->ln_b[l + 1], b, N, 1e-5f, 1, e->lnc);
+        *stage_out = b;
+        if (stop_stage == 3 + 2 * l) return VQCPC_OK;
+    }
+    TRY(vq_gemm_chain(b, CH, e->out_w, e->out_b, zp, 64, N, 64, CH, 256, s));
+    *stage_out = zp;
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode,
+                                    float *z_q, float *c, int64_t *idx, float *z_pre, void *stream) {
+    VQ_REQUIRE(e && mel && z_q && idx, "vqcpc_encoder_encode: null argument");
+    VQ_REQUIRE(B > 0 && T >= 2 && T % 2 == 0, "encoder.encode: need B > 0 and even T >= 2 (got B=%d T=%d)", B, T);
+    VQ_REQUIRE(conv_mode >= 0 && conv_mode <= 2, "encoder.encode: conv_mode must be 0, 1 or 2");
+    hipStream_t s = (hipStream_t)stream;
+    const int To = T / 2, N = B * To;
+    TRY(e->x2.reserve((size_t)N * sizeof(float)));
+    const int npart = e->n_emb / 32;
+    TRY(e->pd.reserve((size_t)N * npart * sizeof(float)));
+    TRY(e->pi.reserve((size_t)N * npart * sizeof(int)));
+    float *zp = z_pre;
+    if (!zp) { TRY(e->zpre.reserve((size_t)N * 64 * sizeof(float))); zp = e->zpre.as<float>(); }
+    VQ_REQUIRE(((uintptr_t)zp & 15) == 0 && ((uintptr_t)z_q & 15) == 0, "encoder.encode: outputs must be 16-byte aligned");
+    const float *unused = nullptr;
+    TRY(encoder_front(e, mel, B, T, conv_mode, 10, zp, &unused, s));
+
+    // VQ (model.py:103-115)
+    hipLaunchKernelGGL(rowsumsq64_kernel, dim3((N + 63) / 64), dim3(64), 0, s, zp, e->x2.as<float>(), N);
+    GemmP q{};
+    q.A = zp; q.lda = 64; q.W = e->codebook; q.M = N; q.N = e->n_emb; q.K = 64; q.KC = 64;
+    q.e2 = e->e2; q.x2 = e->x2.as<float>(); q.pd = e->pd.as<float>(); q.pi = e->pi.as<int>(); q.npart = npart;
+    TRY((launch_gemm<0, 1>(q, s)));
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, e->pd.as<float>(), e->pi.as<int>(),
+                       npart, e->codebook, idx, z_q, N);
+    HIP_TRY(hipGetLastError());
+    if (c) TRY(vq_lstm_run(e->lstm, z_q, B, To, c, s));
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_encoder_stage(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode, int stage,
+                                   float *out, void *stream) {
+    VQ_REQUIRE(e && mel && out, "vqcpc_encoder_stage: null argument");
+    VQ_REQUIRE(B > 0 && T >= 2 && T % 2 == 0 && stage >= 0 && stage <= 10, "vqcpc_encoder_stage: bad shape or stage");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = B * (T / 2);
+    const float *src = nullptr;
+    float *zp = nullptr;
+    if (stage == 10) {
+        VQ_REQUIRE(((uintptr_t)out & 15) == 0, "vqcpc_encoder_stage: out must be 16-byte aligned");
+        zp = out;
+    }
+    TRY(encoder_front(e, mel, B, T, conv_mode, stage, zp, &src, s));
+    if (stage != 10)
+        HIP_TRY(hipMemcpyAsync(out, src, (size_t)N * e->channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_encoder_context(vqcpc_encoder *e, const float *z, int B, int Tz, float *c, void *stream) {
+    VQ_REQUIRE(e && z && c && B > 0 && Tz > 0, "vqcpc_encoder_context: bad argument");
+    return vq_lstm_run(e->lstm, z, B, Tz, c, (hipStream_t)stream);
+}
+
+extern "C" int vqcpc_encoder_forward_stats(vqcpc_encoder *e, const float *z_pre, const float *z_q,
+                                           const int64_t *idx, int n_rows, float *z_st, float *loss,
+                                           float *perplexity, void *stream) {
+    VQ_REQUIRE(e && z_pre && z_q && idx && loss && perplexity && n_rows > 0, "vqcpc_encoder_forward_stats: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = 64;
+    const size_t hist_bytes = (size_t)e->n_emb * sizeof(unsigned);
+    TRY(e->stats.reserve(hist_bytes + nblk * sizeof(double) + 64));
+    unsigned *hist = e->stats.as<unsigned>();
+    double *part = (double *)((char *)e->stats.p + ((hist_bytes + 15) / 16) * 16);
+    HIP_TRY(hipMemsetAsync(hist, 0, hist_bytes, s));
+    hipLaunchKernelGGL(vq_stats_partial_kernel, dim3(nblk), dim3(256), 0, s, z_pre, z_q, idx, n_rows, z_st, part, hist);
+    hipLaunchKernelGGL(vq_stats_final_kernel, dim3(1), dim3(256), 0, s, part, nblk, hist, e->n_emb, n_rows, loss, perplexity);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}

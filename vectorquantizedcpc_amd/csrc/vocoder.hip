@@ -1,0 +1,724 @@
+// vocoder.hip -- Vocoder.generate / Vocoder.forward on gfx950 (reference call sites
+// network_vocoder.py:41-78; the RNN_MS arithmetic is the project's spec of the absent
+// third-party `rnnms` package -- see oracle/vqcpc_oracle.c and DESIGN.md), plus the
+// recurrent-step machinery the encoder's LSTM (model.py:57, :69) shares.
+//
+// Design (DESIGN.md "Decode loop"): every recurrence is WEIGHT-STATIONARY across the chip
+// and BATCHED over utterances.  One step = a skinny fp32 GEMM [rows x K] x [K x B]; each
+// workgroup owns 16 gate rows (4 hidden units x their gates), streams its own 16 x K weight
+// fragment from L2 (fragment-ordered, 16 B per lane), multiplies it with the whole state
+// matrix h (K x 16-utterance tiles) on v_mfma_f32_16x16x4_f32, reduces the 4 K-quarters
+// through LDS and applies the cell update.  The all-gather of h between steps is the kernel
+// boundary; the per-sample kernels are replayed from a hipGraph.
+#include "common.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <vector>
+
+int vq_require_gfx950();
+#define TRY(x) do { int rc_ = (x); if (rc_ != VQCPC_OK) return rc_; } while (0)
+
+// state layout "hL": h[b][k] at ((b/16) * (K/4) + k/4) * 64 + (b%16) * 4 + k%4
+__device__ __forceinline__ size_t hl_index(int K, int b, int k) {
+    return ((size_t)(b >> 4) * (K >> 2) + (k >> 2)) * 64 + (b & 15) * 4 + (k & 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fragment-ordered weights.  For row group `rg` (16 rows, row_of(rg, i) or -1 = zero row),
+// K split over `ksplit` waves, super-step S = 16 consecutive k:
+//   Wf[((rg*ksplit + w)*SW + s)*64 + lane] (float4) = W[row_of(rg, lane&15)][16*S + 4*(lane>>4) + 0..3]
+// with S = w*SW + s.  rowmode: 0 plain (row = 16 rg + i), 3 GRU gates, 4 LSTM gates
+// (row = gate*H + 4 rg + i%4, gate = i/4; rows >= G*4 are zero).
+// ------------------------------------------------------------------------------------------
+__global__ void build_wfrag_kernel(const float *__restrict__ W, int ldw, float *__restrict__ Wf, int n_rg,
+                                   int K, int ksplit, int rowmode, int H) {
+    const int SW = K / 16 / ksplit;
+    const size_t total = (size_t)n_rg * ksplit * SW * 64;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int lane = (int)(id & 63);
+    size_t r = id >> 6;
+    const int s = (int)(r % SW); r /= SW;
+    const int w = (int)(r % ksplit);
+    const int rg = (int)(r / ksplit);
+    const int i = lane & 15, kq = lane >> 4, S = w * SW + s;
+    int row;
+    if (rowmode == 0) row = 16 * rg + i;
+    else row = (i >> 2) < rowmode ? (i >> 2) * H + 4 * rg + (i & 3) : -1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= 0) v = *(const float4 *)(W + (size_t)row * ldw + 16 * S + 4 * kq);
+    ((float4 *)Wf)[id] = v;
+}
+
+static int build_wfrag(const float *W, int ldw, int n_rg, int K, int ksplit, int rowmode, int H, float **out) {
+    VQ_REQUIRE(K % (16 * ksplit) == 0 && ldw % 4 == 0, "build_wfrag: K=%d not a multiple of %d", K, 16 * ksplit);
+    const size_t n4 = (size_t)n_rg * (K / 16) * 64;
+    HIP_TRY(hipMalloc((void **)out, n4 * sizeof(float4)));
+    hipLaunchKernelGGL(build_wfrag_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, W, ldw, *out, n_rg, K,
+                       ksplit, rowmode, H);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+template <int SW>
+__device__ __forceinline__ void load_wfrag(const float *Wf, int rg, int ksplit, int wave, int lane, float4 (&wf)[SW]) {
+    const float4 *p = (const float4 *)Wf + ((size_t)(rg * ksplit + wave) * SW) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < SW; ++s) wf[s] = p[s * 64];
+}
+
+// 16 rows x 16 utterances partial product over this wave's K quarter.
+template <int SW>
+__device__ __forceinline__ f32x4 mv16(const float4 (&wf)[SW], const float *hL, int K, int bt, int wave, int lane) {
+    const float4 *hp = (const float4 *)hL + ((size_t)bt * (K >> 2)) * 16 + (size_t)wave * SW * 64 + lane;
+    float4 hv[SW];
+#pragma unroll
+    for (int s = 0; s < SW; ++s) hv[s] = hp[s * 64];
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv[s].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv[s].y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv[s].z, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv[s].w, a1, 0, 0, 0);
+    }
+    return a0 + a1;
+}
+
+// cross-wave reduction of the 4 K-quarters: red[wave][row][b] -> returns sum for (row=tid>>4, b=tid&15)
+__device__ __forceinline__ float reduce4(float (*red)[16][17], const f32x4 &acc, int wave, int lane, int tid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    __syncthreads();
+    const int row = tid >> 4, b = tid & 15;
+    return ((red[0][row][b] + red[1][row][b]) + red[2][row][b]) + red[3][row][b];
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// ------------------------------------------------------------------------------------------
+// Sequence recurrences with a hoisted input projection (prenet bi-GRU, encoder LSTM).
+// ------------------------------------------------------------------------------------------
+struct SeqP {
+    const float *Wf;      // [dir][H/4 row groups][4 waves][SW][64] float4
+    const float *b_hh;    // GRU: [dir][3H]; LSTM: unused (folded into Gi)
+    const float *Gi;      // [B*T][ndir*G*H]  input projection (+ biases)
+    float *hbuf;          // [2][ndir][nbt][H*16]
+    float *cbuf;          // LSTM cell state [ndir][nbt][H*16]
+    float *out;           // [B][T][ndir*H]
+    const int *len;       // valid steps per utterance (nbt*16) or null = T for b < B
+    int H, nbt, B, T, ndir;
+};
+
+template <int G, int SW>   // G = 3 GRU, 4 LSTM
+__global__ __launch_bounds__(256) void seq_step_kernel(SeqP p, int step) {
+    __shared__ float red[4][16][17];
+    __shared__ float gate[16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = blockIdx.x, dir = blockIdx.y, H = p.H;
+    const size_t hsz = (size_t)p.nbt * H * 16;
+    const float *hin = p.hbuf + ((size_t)(step & 1) * p.ndir + dir) * hsz;
+    float *hout = p.hbuf + ((size_t)((step + 1) & 1) * p.ndir + dir) * hsz;
+    float4 wf[SW];
+    load_wfrag<SW>(p.Wf + (size_t)dir * (H / 4) * (H / 16) * 64 * 4, rg, 4, wave, lane, wf);
+    for (int bt = 0; bt < p.nbt; ++bt) {
+        const f32x4 acc = mv16<SW>(wf, hin, H, bt, wave, lane);
+        const float v = reduce4(red, acc, wave, lane, tid);
+        gate[tid >> 4][tid & 15] = v;
+        __syncthreads();
+        if (tid < 64) {
+            const int u = tid >> 4, b = tid & 15, bg = bt * 16 + b;
+            const int L = p.len ? p.len[bg] : (bg < p.B ? p.T : 0);
+            if (step < L) {
+                const int tpos = dir == 0 ? step : L - 1 - step;
+                const int unit = 4 * rg + u;
+                const float *gi = p.Gi + ((size_t)bg * p.T + tpos) * (p.ndir * G * H) + (size_t)dir * G * H + unit;
+                const size_t hi = hl_index(H, bg, unit);
+                float hn;
+                if (G == 3) {
+                    const float *bh = p.b_hh + (size_t)dir * 3 * H + unit;
+                    const float r = sigmoidf_(gi[0] + (gate[u][b] + bh[0]));
+                    const float z = sigmoidf_(gi[H] + (gate[4 + u][b] + bh[H]));
+                    const float n = tanhf(gi[2 * H] + r * (gate[8 + u][b] + bh[2 * H]));
+                    hn = (1.0f - z) * n + z * hin[hi];
+                } else {
+                    float *cs = p.cbuf + (size_t)dir * hsz + hi;
+                    const float ig = sigmoidf_(gi[0] + gate[u][b]), fg = sigmoidf_(gi[H] + gate[4 + u][b]);
+                    const float gg = tanhf(gi[2 * H] + gate[8 + u][b]), og = sigmoidf_(gi[3 * H] + gate[12 + u][b]);
+                    const float cn = fg * (*cs) + ig * gg;
+                    *cs = cn;
+                    hn = og * tanhf(cn);
+                }
+                hout[hi] = hn;
+                p.out[((size_t)bg * p.T + tpos) * (p.ndir * H) + (size_t)dir * H + unit] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int G>
+static int launch_seq(const SeqP &p, int step, hipStream_t s) {
+    const int SW = p.H / 64;
+    dim3 grid(p.H / 4, p.ndir), blk(256);
+    switch (SW) {
+#define CASE(n) case n: hipLaunchKernelGGL((seq_step_kernel<G, n>), grid, blk, 0, s, p, step); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+#undef CASE
+        default: vq_set_error("recurrent step: hidden size %d unsupported (H/64 = %d)", p.H, SW); return VQCPC_ERR_INVALID;
+    }
+    return VQCPC_OK;
+}
+
+__global__ void add_vec_kernel(const float *a, const float *b, float *o, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+// ---- encoder LSTM plan (model.py:57)
+struct LstmPlan {
+    int D, H;
+    float *w_ih = nullptr, *bias = nullptr, *Wf = nullptr;
+    DevBuf gi, hbuf, cbuf;
+};
+void vq_lstm_plan_destroy(LstmPlan *p) {
+    if (!p) return;
+    if (p->w_ih) (void)hipFree(p->w_ih);
+    if (p->bias) (void)hipFree(p->bias);
+    if (p->Wf) (void)hipFree(p->Wf);
+    p->gi.release(); p->hbuf.release(); p->cbuf.release();
+    delete p;
+}
+int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int D, int H,
+                        LstmPlan **out) {
+    VQ_REQUIRE(D % 32 == 0 && H % 64 == 0, "LSTM: need D %% 32 == 0 and H %% 64 == 0 (got %d, %d)", D, H);
+    LstmPlan *p = new LstmPlan();
+    p->D = D; p->H = H;
+    *out = p;
+    HIP_TRY(hipMalloc((void **)&p->w_ih, (size_t)4 * H * D * sizeof(float)));
+    HIP_TRY(hipMemcpy(p->w_ih, w_ih, (size_t)4 * H * D * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMalloc((void **)&p->bias, (size_t)4 * H * sizeof(float)));
+    hipLaunchKernelGGL(add_vec_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, 0, b_ih, b_hh, p->bias, 4 * H);
+    HIP_TRY(hipGetLastError());
+    TRY(build_wfrag(w_hh, H, H / 4, H, 4, 4, H, &p->Wf));
+    return VQCPC_OK;
+}
+int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream_t s) {
+    const int H = p->H, nbt = (B + 15) / 16;
+    TRY(p->gi.reserve((size_t)B * T * 4 * H * sizeof(float)));
+    const size_t hsz = (size_t)nbt * H * 16 * sizeof(float);
+    TRY(p->hbuf.reserve(2 * hsz));
+    TRY(p->cbuf.reserve(hsz));
+    TRY(vq_gemm_chain(x, p->D, p->w_ih, p->bias, p->gi.as<float>(), 4 * H, B * T, 4 * H, p->D, p->D, s));
+    HIP_TRY(hipMemsetAsync(p->hbuf.p, 0, 2 * hsz, s));
+    HIP_TRY(hipMemsetAsync(p->cbuf.p, 0, hsz, s));
+    SeqP q{};
+    q.Wf = p->Wf; q.Gi = p->gi.as<float>(); q.hbuf = p->hbuf.as<float>(); q.cbuf = p->cbuf.as<float>();
+    q.out = out; q.len = nullptr; q.H = H; q.nbt = nbt; q.B = B; q.T = T; q.ndir = 1;
+    for (int t = 0; t < T; ++t) TRY(launch_seq<4>(q, t, s));
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Autoregressive sample loop: GRU step -> fc1 -> (fc2 + softmax + inverse-CDF draw + mu-law).
+// Per-call quantities live in a device-side ArCall so one captured graph serves every call.
+// ------------------------------------------------------------------------------------------
+struct ArCall {
+    const float *Gcond;        // [Bpad][F][3Hr] = W_ih[:, de:] cond + b_ih
+    const int64_t *inputs;     // teacher forcing (B, Ts) or null
+    float *wav;                // (B, Lout) or null
+    int64_t *mulaw;            // (B, Lout) or null
+    float *logits;             // (B, Ts, n_cls) or null
+    int F, Ts, Lout, max_t, nbt;
+    unsigned long long seed;
+    unsigned utt_base;
+    int t_base;                // advanced on device after every graph replay
+};
+
+struct ArModel {               // constant per handle
+    const float *Wf_hh, *b_hh, *Gemb;
+    const float *Wf_fc1, *b_fc1, *Wf_fc2, *b_fc2, *mulaw_tab;
+    float *hbuf;               // [2][nbt][Hr*16]
+    float *a1;                 // [nbt][Hf*16]
+    int *xprev;                // [Bpad]
+    const int *len;            // [Bpad] samples per utterance
+    int Hr, Hf, n_cls, upsample;
+};
+
+template <int SW>
+__global__ __launch_bounds__(256) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
+    __shared__ float red[4][16][17];
+    __shared__ float gate[16][17];
+    const ArCall c = *cp;
+    const int t = c.t_base + t_local;
+    if (t >= c.max_t) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, Hr = m.Hr;
+    const size_t hsz = (size_t)c.nbt * Hr * 16;
+    const float *hin = m.hbuf + (size_t)(t & 1) * hsz;
+    float *hout = m.hbuf + (size_t)((t + 1) & 1) * hsz;
+    float4 wf[SW];
+    load_wfrag<SW>(m.Wf_hh, rg, 4, wave, lane, wf);
+    const int frame = t / m.upsample;
+    for (int bt = 0; bt < c.nbt; ++bt) {
+        const f32x4 acc = mv16<SW>(wf, hin, Hr, bt, wave, lane);
+        const float v = reduce4(red, acc, wave, lane, tid);
+        gate[tid >> 4][tid & 15] = v;
+        __syncthreads();
+        if (tid < 64) {
+            const int u = tid >> 4, b = tid & 15, bg = bt * 16 + b;
+            if (t < m.len[bg]) {
+                int x = c.inputs ? (int)c.inputs[(size_t)bg * c.Ts + t] : (t == 0 ? m.n_cls / 2 : m.xprev[bg]);
+                x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
+                const int unit = 4 * rg + u;
+                const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
+                const float *gc = c.Gcond + ((size_t)bg * c.F + frame) * 3 * Hr + unit;
+                const float *bh = m.b_hh + unit;
+                const size_t hi = hl_index(Hr, bg, unit);
+                const float r = sigmoidf_((ge[0] + gc[0]) + (gate[u][b] + bh[0]));
+                const float z = sigmoidf_((ge[Hr] + gc[Hr]) + (gate[4 + u][b] + bh[Hr]));
+                const float n = tanhf((ge[2 * Hr] + gc[2 * Hr]) + r * (gate[8 + u][b] + bh[2 * Hr]));
+                hout[hi] = (1.0f - z) * n + z * hin[hi];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int SW>
+__global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
+    __shared__ float red[4][16][17];
+    const ArCall c = *cp;
+    const int t = c.t_base + t_local;
+    if (t >= c.max_t) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x;
+    const float *h = m.hbuf + (size_t)((t + 1) & 1) * c.nbt * m.Hr * 16;
+    float4 wf[SW];
+    load_wfrag<SW>(m.Wf_fc1, rg, 4, wave, lane, wf);
+    for (int bt = 0; bt < c.nbt; ++bt) {
+        const f32x4 acc = mv16<SW>(wf, h, m.Hr, bt, wave, lane);
+        float v = reduce4(red, acc, wave, lane, tid);
+        const int row = 16 * rg + (tid >> 4), bg = bt * 16 + (tid & 15);
+        v += m.b_fc1[row];
+        m.a1[hl_index(m.Hf, bg, row)] = v > 0.f ? v : 0.f;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ unsigned philox_word0(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
+    unsigned c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c[0];
+}
+
+// One workgroup per 16-utterance tile: 16 waves = the 16 row groups of fc2 (n_cls = 256),
+// then wave w draws the sample of utterance w.
+__global__ __launch_bounds__(1024) void ar_head_kernel(ArModel m, ArCall *__restrict__ cp, int t_local) {
+    __shared__ float4 a1s[1024];           // a1 tile, fragment order (Hf = 256: 16 super-steps x 64 lanes)
+    __shared__ float lg[16][260];
+    const ArCall c = *cp;
+    const int t = c.t_base + t_local;
+    if (t >= c.max_t) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bt = blockIdx.x;
+    const int NS = m.Hf / 16;              // 16
+    for (int i = tid; i < NS * 64; i += 1024) a1s[i] = ((const float4 *)m.a1)[(size_t)bt * NS * 64 + i];
+    float4 wf[16];
+    load_wfrag<16>(m.Wf_fc2, wave, 1, 0, lane, wf);
+    __syncthreads();
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float4 hv = a1s[s * 64 + lane];
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv.x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv.y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv.z, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv.w, a3, 0, 0, 0);
+    }
+    const f32x4 acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + (lane >> 4) * 4 + r;
+        lg[lane & 15][row] = acc[r] + m.b_fc2[row];
+    }
+    __syncthreads();
+
+    const int bg = bt * 16 + wave;
+    if (t >= m.len[bg]) return;                       // wave-uniform
+    float v[4], e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = lg[wave][4 * lane + i];
+    if (c.logits) *(float4 *)(c.logits + ((size_t)bg * c.Ts + t) * 256 + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+    float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = expf(v[i] - mx);
+    const float p0 = e[0], p1 = p0 + e[1], p2 = p1 + e[2], p3 = p2 + e[3];
+    float incl = p3;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0.f;
+    const float total = __shfl(incl, 63);
+    const unsigned w0 = philox_word0((unsigned)t, c.utt_base + (unsigned)bg, (unsigned)c.seed, (unsigned)(c.seed >> 32));
+    const float uni = (float)(w0 >> 8) * (1.0f / 16777216.0f);
+    const float thr = uni * total;
+    const unsigned long long mask = __ballot(excl + p3 > thr);
+    int s = m.n_cls - 1;
+    if (mask) {
+        const int lf = __ffsll((unsigned long long)mask) - 1;
+        int mine = (excl + p0 > thr) ? 0 : (excl + p1 > thr) ? 1 : (excl + p2 > thr) ? 2 : 3;
+        s = 4 * lf + __shfl(mine, lf);
+    }
+    if (lane == 0) {
+        m.xprev[bg] = s;
+        if (c.wav) c.wav[(size_t)bg * c.Lout + t] = m.mulaw_tab[s];
+        if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + t] = s;
+    }
+}
+
+__global__ void ar_advance_kernel(ArCall *c, int n) { c->t_base += n; }
+
+// Vocoder glue (network_vocoder.py:73-77): series[b, t2, :dz] = code_emb[idx[b, t2/2]], [dz:] = spk_emb[spk[b]]
+__global__ void glue_kernel(const int64_t *__restrict__ idx, const int64_t *__restrict__ spk,
+                            const float *__restrict__ ce, const float *__restrict__ se, float *__restrict__ out,
+                            int B, int Tc, int dz, int ds, int n_codes, int n_spk) {
+    const int F = dz + ds;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * 2 * Tc * F) return;
+    const int f = (int)(i % F);
+    const size_t r = i / F;
+    const int t2 = (int)(r % (2 * Tc)), b = (int)(r / (2 * Tc));
+    if (f < dz) {
+        long long z = idx[(size_t)b * Tc + t2 / 2];
+        z = z < 0 ? 0 : (z >= n_codes ? n_codes - 1 : z);
+        out[i] = ce[(size_t)z * dz + f];
+    } else {
+        long long sp = spk[b];
+        sp = sp < 0 ? 0 : (sp >= n_spk ? n_spk - 1 : sp);
+        out[i] = se[(size_t)sp * ds + (f - dz)];
+    }
+}
+
+__global__ void copy_submatrix_kernel(const float *__restrict__ src, int ld, int col0, float *__restrict__ dst,
+                                      int rows, int cols) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int r = (int)(i / cols), cidx = (int)(i % cols);
+    dst[i] = src[(size_t)r * ld + col0 + cidx];
+}
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct vqcpc_vocoder {
+    vqcpc_vocoder_weights d;             // dims only (pointers below are owned copies)
+    float *code_emb = nullptr, *spk_emb = nullptr;
+    float *p_wih[2] = {}, *p_bih[2] = {}, *p_bhh[2] = {}, *p_wf[2] = {};   // per layer, both directions stacked
+    float *w_cond = nullptr, *b_ih = nullptr, *Gemb = nullptr;
+    float *Wf_hh = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
+    float *mulaw_tab = nullptr;
+    ArCall *call = nullptr;              // device
+    DevBuf series, gi, out0, cond, gcond, hseq, har, a1, xprev, len;
+    int use_graph = 1, steps_per_graph = 160;
+    std::map<int, hipGraphExec_t> graphs; // key: nbt
+    hipStream_t cap_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_steps = 0;
+    const void *baked[4] = {nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
+};
+
+static int dcopy(float **dst, const float *src, size_t n) {
+    HIP_TRY(hipMalloc((void **)dst, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return VQCPC_OK;
+}
+
+extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
+    if (!v) return;
+    for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+    float *ptrs[] = {v->code_emb, v->spk_emb, v->p_wih[0], v->p_wih[1], v->p_bih[0], v->p_bih[1], v->p_bhh[0],
+                     v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh, v->b_hh,
+                     v->Wf_fc1, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
+    for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (v->call) (void)hipFree(v->call);
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->har, &v->a1, &v->xprev, &v->len};
+    for (DevBuf *b : bufs) b->release();
+    if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
+    if (v->ev0) (void)hipEventDestroy(v->ev0);
+    if (v->ev1) (void)hipEventDestroy(v->ev1);
+    delete v;
+}
+
+static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v) {
+    v->d = *w;
+    const int F = w->dz + w->ds, Hp = w->Hp, dl = 2 * Hp, Hr = w->Hr, de = w->de;
+    TRY(dcopy(&v->code_emb, w->code_embedding, (size_t)w->n_codes * w->dz));
+    TRY(dcopy(&v->spk_emb, w->speaker_embedding, (size_t)w->n_speakers * w->ds));
+    for (int l = 0; l < 2; ++l) {
+        const int I = l == 0 ? F : dl;
+        HIP_TRY(hipMalloc((void **)&v->p_wih[l], (size_t)6 * Hp * I * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&v->p_bih[l], (size_t)6 * Hp * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&v->p_bhh[l], (size_t)6 * Hp * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&v->p_wf[l], (size_t)2 * (Hp / 4) * (Hp / 16) * 64 * sizeof(float4)));
+        for (int d = 0; d < 2; ++d) {
+            HIP_TRY(hipMemcpy(v->p_wih[l] + (size_t)d * 3 * Hp * I, w->prenet_w_ih[l][d], (size_t)3 * Hp * I * sizeof(float), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(v->p_bih[l] + (size_t)d * 3 * Hp, w->prenet_b_ih[l][d], (size_t)3 * Hp * sizeof(float), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(v->p_bhh[l] + (size_t)d * 3 * Hp, w->prenet_b_hh[l][d], (size_t)3 * Hp * sizeof(float), hipMemcpyDeviceToDevice));
+            float *tmp = nullptr;
+            TRY(build_wfrag(w->prenet_w_hh[l][d], Hp, Hp / 4, Hp, 4, 3, Hp, &tmp));
+            const size_t nb = (size_t)(Hp / 4) * (Hp / 16) * 64 * sizeof(float4);
+            HIP_TRY(hipMemcpy((char *)v->p_wf[l] + d * nb, tmp, nb, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipFree(tmp));
+        }
+    }
+    // AR input weights split: [:, :de] feeds the sample embedding (-> lookup table Gemb), [:, de:] the conditioning
+    float *w_emb = nullptr;
+    HIP_TRY(hipMalloc((void **)&w_emb, (size_t)3 * Hr * de * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&v->w_cond, (size_t)3 * Hr * dl * sizeof(float)));
+    hipLaunchKernelGGL(copy_submatrix_kernel, dim3((unsigned)(((size_t)3 * Hr * de + 255) / 256)), dim3(256), 0, 0,
+                       w->ar_w_ih, de + dl, 0, w_emb, 3 * Hr, de);
+    hipLaunchKernelGGL(copy_submatrix_kernel, dim3((unsigned)(((size_t)3 * Hr * dl + 255) / 256)), dim3(256), 0, 0,
+                       w->ar_w_ih, de + dl, de, v->w_cond, 3 * Hr, dl);
+    HIP_TRY(hipGetLastError());
+    TRY(dcopy(&v->b_ih, w->ar_b_ih, (size_t)3 * Hr));
+    TRY(dcopy(&v->b_hh, w->ar_b_hh, (size_t)3 * Hr));
+    HIP_TRY(hipMalloc((void **)&v->Gemb, (size_t)w->n_cls * 3 * Hr * sizeof(float)));
+    float *emb = nullptr;
+    TRY(dcopy(&emb, w->ar_embedding, (size_t)w->n_cls * de));
+    TRY(vq_gemm_chain(emb, de, w_emb, nullptr, v->Gemb, 3 * Hr, w->n_cls, 3 * Hr, de, de, 0));
+    TRY(build_wfrag(w->ar_w_hh, Hr, Hr / 4, Hr, 4, 3, Hr, &v->Wf_hh));
+    TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 16, Hr, 4, 0, 0, &v->Wf_fc1));
+    TRY(build_wfrag(w->fc2_weight, w->Hf, w->n_cls / 16, w->Hf, 1, 0, 0, &v->Wf_fc2));
+    TRY(dcopy(&v->b_fc1, w->fc1_bias, w->Hf));
+    TRY(dcopy(&v->b_fc2, w->fc2_bias, w->n_cls));
+    // mu-law decode table (preprocess.py:30-35, evaluated in float64 like the reference's numpy)
+    std::vector<float> tab(w->n_cls);
+    const double mu = (double)((1 << w->bits_mu_law) - 1);
+    for (int s = 0; s < w->n_cls; ++s) {
+        const double y = 2.0 * (double)s / mu - 1.0, sg = (y > 0) - (y < 0);
+        tab[s] = (float)(sg / mu * (pow(1.0 + mu, fabs(y)) - 1.0));
+    }
+    HIP_TRY(hipMalloc((void **)&v->mulaw_tab, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(v->mulaw_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&v->call, sizeof(ArCall)));
+    HIP_TRY(hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&v->ev0));
+    HIP_TRY(hipEventCreate(&v->ev1));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(w_emb));
+    HIP_TRY(hipFree(emb));
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_vocoder_create(const vqcpc_vocoder_weights *w, vqcpc_vocoder **out) {
+    VQ_REQUIRE(w && out, "vqcpc_vocoder_create: null argument");
+    *out = nullptr;
+    TRY(vq_require_gfx950());
+    VQ_REQUIRE(w->n_cls == 256 && w->bits_mu_law == 8, "vocoder: n_cls must be 256 (bits_mu_law 8)");
+    VQ_REQUIRE(w->Hf == 256, "vocoder: size_h_fc must be 256 (got %d)", w->Hf);
+    VQ_REQUIRE((w->dz + w->ds) % 32 == 0 && w->Hp % 64 == 0 && w->Hp <= 1024, "vocoder: dz+ds %% 32 and Hp %% 64 required");
+    VQ_REQUIRE(w->Hr % 64 == 0 && w->Hr <= 1024 && w->de % 32 == 0, "vocoder: Hr %% 64 and de %% 32 required (got %d, %d)", w->Hr, w->de);
+    VQ_REQUIRE(w->upsample_t > 0, "vocoder: upsample_t must be positive");
+    vqcpc_vocoder *v = new vqcpc_vocoder();
+    int rc = vocoder_create_impl(w, v);
+    if (rc != VQCPC_OK) { vqcpc_vocoder_destroy(v); return rc; }
+    *out = v;
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int value) {
+    VQ_REQUIRE(v && name, "vqcpc_vocoder_set_option: null argument");
+    if (!strcmp(name, "use_graph")) { v->use_graph = value != 0; return VQCPC_OK; }
+    if (!strcmp(name, "steps_per_graph")) {
+        VQ_REQUIRE(value > 0 && value <= 4096, "steps_per_graph out of range");
+        if (value != v->steps_per_graph) {
+            for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+            v->graphs.clear();
+        }
+        v->steps_per_graph = value;
+        return VQCPC_OK;
+    }
+    vq_set_error("unknown option %s", name);
+    return VQCPC_ERR_INVALID;
+}
+
+extern "C" int vqcpc_vocoder_last_timing(vqcpc_vocoder *v, float *loop_ms, int *n_steps) {
+    VQ_REQUIRE(v && loop_ms && n_steps, "vqcpc_vocoder_last_timing: null argument");
+    HIP_TRY(hipEventElapsedTime(loop_ms, v->ev0, v->ev1));
+    *n_steps = v->last_steps;
+    return VQCPC_OK;
+}
+
+// conditioning: glue -> 2-layer bi-GRU prenet -> cond (B, 2Tc, 2Hp); lens_dev = valid frames per utterance
+static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int B, int Tc,
+                         const int *frames_dev, float *cond_out, hipStream_t s) {
+    const auto &d = v->d;
+    const int F = d.dz + d.ds, Hp = d.Hp, dl = 2 * Hp, T2 = 2 * Tc, nbt = (B + 15) / 16;
+    const size_t rows = (size_t)B * T2;
+    TRY(v->series.reserve(rows * F * sizeof(float)));
+    TRY(v->gi.reserve(rows * 6 * Hp * sizeof(float)));
+    TRY(v->out0.reserve(rows * dl * sizeof(float)));
+    const size_t hsz = (size_t)2 * nbt * Hp * 16 * sizeof(float);
+    TRY(v->hseq.reserve(2 * hsz));
+    const size_t ng = rows * F;
+    hipLaunchKernelGGL(glue_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, idx, spk, v->code_emb,
+                       v->spk_emb, v->series.as<float>(), B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers);
+    for (int l = 0; l < 2; ++l) {
+        const float *xin = l == 0 ? v->series.as<float>() : v->out0.as<float>();
+        const int I = l == 0 ? F : dl;
+        float *xout = l == 0 ? v->out0.as<float>() : cond_out;
+        TRY(vq_gemm_chain(xin, I, v->p_wih[l], v->p_bih[l], v->gi.as<float>(), 6 * Hp, (int)rows, 6 * Hp, I, I, s));
+        HIP_TRY(hipMemsetAsync(v->hseq.p, 0, 2 * hsz, s));
+        if (frames_dev) HIP_TRY(hipMemsetAsync(xout, 0, rows * dl * sizeof(float), s));
+        SeqP q{};
+        q.Wf = v->p_wf[l]; q.b_hh = v->p_bhh[l]; q.Gi = v->gi.as<float>(); q.hbuf = v->hseq.as<float>();
+        q.out = xout; q.len = frames_dev; q.H = Hp; q.nbt = nbt; q.B = B; q.T = T2; q.ndir = 2;
+        for (int t = 0; t < T2; ++t) TRY(launch_seq<3>(q, t, s));
+    }
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, hipStream_t s) {
+    const int SW = v->d.Hr / 64;
+    const dim3 blk(256);
+    for (int i = 0; i < n; ++i) {
+        switch (SW) {
+#define CASE(k) case k: \
+            hipLaunchKernelGGL((ar_gru_kernel<k>), dim3(v->d.Hr / 4), blk, 0, s, m, (const ArCall *)v->call, i); \
+            hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16), blk, 0, s, m, (const ArCall *)v->call, i); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+#undef CASE
+            default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
+        }
+        hipLaunchKernelGGL(ar_head_kernel, dim3(nbt), dim3(1024), 0, s, m, v->call, i);
+    }
+    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, v->call, n);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+// Shared driver of generate() and logits().
+static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int B, int Tc, const int *n_codes_host,
+                  const int64_t *inputs, int Ts, unsigned long long seed, unsigned utt_base, float *wav,
+                  int64_t *mulaw, float *logits, int max_steps, hipStream_t s) {
+    const auto &d = v->d;
+    const int Hr = d.Hr, dl = 2 * d.Hp, T2 = 2 * Tc, nbt = (B + 15) / 16, Bp = nbt * 16;
+    const int Lout = d.upsample_t * T2;
+    // per-utterance lengths: frames for the prenet, samples for the AR loop
+    std::vector<int> lens(2 * Bp, 0);
+    int max_t = 0;
+    bool ragged = false;
+    for (int b = 0; b < B; ++b) {
+        int nc = n_codes_host ? n_codes_host[b] : Tc;
+        VQ_REQUIRE(nc >= 0 && nc <= Tc, "vocoder: n_codes[%d] = %d outside [0, %d]", b, nc, Tc);
+        ragged |= nc != Tc;
+        lens[b] = 2 * nc;
+        int ns = d.upsample_t * 2 * nc;
+        if (inputs) ns = ns < Ts ? ns : Ts;
+        if (max_steps > 0 && ns > max_steps) ns = max_steps;
+        lens[Bp + b] = ns;
+        max_t = ns > max_t ? ns : max_t;
+    }
+    TRY(v->len.reserve(lens.size() * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(v->len.p, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));     // lens is a stack-lifetime host buffer
+    const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
+    const int *samples_dev = v->len.as<int>() + Bp;
+
+    const size_t rows = (size_t)B * T2;
+    TRY(v->cond.reserve(rows * dl * sizeof(float)));
+    TRY(run_condition(v, idx, spk, B, Tc, frames_dev, v->cond.as<float>(), s));
+    TRY(v->gcond.reserve((size_t)Bp * T2 * 3 * Hr * sizeof(float)));
+    TRY(vq_gemm_chain(v->cond.as<float>(), dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)rows, 3 * Hr, dl, dl, s));
+
+    const size_t hsz = (size_t)nbt * Hr * 16 * sizeof(float);
+    TRY(v->har.reserve(2 * hsz));
+    TRY(v->a1.reserve((size_t)nbt * d.Hf * 16 * sizeof(float)));
+    TRY(v->xprev.reserve(Bp * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(v->har.p, 0, 2 * hsz, s));
+    HIP_TRY(hipMemsetAsync(v->xprev.p, 0, Bp * sizeof(int), s));
+    if (wav && (ragged || max_steps > 0)) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
+    if (mulaw && (ragged || max_steps > 0)) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
+
+    ArCall c{};
+    c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
+    c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.utt_base = utt_base; c.t_base = 0;
+    HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));     // c is a stack-lifetime host buffer
+
+    ArModel m{};
+    m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.b_fc1 = v->b_fc1;
+    m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
+    m.hbuf = v->har.as<float>(); m.a1 = v->a1.as<float>(); m.xprev = v->xprev.as<int>(); m.len = samples_dev;
+    m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
+
+    const int S = v->steps_per_graph;
+    HIP_TRY(hipEventRecord(v->ev0, s));
+    if (v->use_graph) {
+        // The graph bakes ArModel (buffer pointers): drop cached graphs if a workspace moved.
+        const void *now[4] = {v->har.p, v->a1.p, v->xprev.p, v->len.p};
+        if (memcmp(v->baked, now, sizeof now) != 0) {
+            for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+            v->graphs.clear();
+            memcpy(v->baked, now, sizeof now);
+        }
+        auto it = v->graphs.find(nbt);
+        if (it == v->graphs.end()) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = launch_ar_steps(v, m, nbt, S, v->cap_stream);
+            hipError_t e = hipStreamEndCapture(v->cap_stream, &g);
+            if (rc != VQCPC_OK) return rc;
+            HIP_TRY(e);
+            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphDestroy(g));
+            it = v->graphs.emplace(nbt, ge).first;
+        }
+        for (int t0 = 0; t0 < max_t; t0 += S) HIP_TRY(hipGraphLaunch(it->second, s));
+    } else {
+        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, nbt, S, s));
+    }
+    HIP_TRY(hipEventRecord(v->ev1, s));
+    v->last_steps = max_t;
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_vocoder_generate(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc,
+                                      const int *n_codes, uint64_t seed, uint32_t utt_base, float *wav,
+                                      int64_t *mulaw, int max_steps, void *stream) {
+    VQ_REQUIRE(v && idx && speaker && wav, "vqcpc_vocoder_generate: null argument");
+    VQ_REQUIRE(B > 0 && Tc > 0, "vocoder.generate: need B > 0 and Tc > 0 (got %d, %d)", B, Tc);
+    return run_ar(v, idx, speaker, B, Tc, n_codes, nullptr, 0, seed, utt_base, wav, mulaw, nullptr, max_steps,
+                  (hipStream_t)stream);
+}
+
+extern "C" int vqcpc_vocoder_logits(vqcpc_vocoder *v, const int64_t *x, const int64_t *idx, const int64_t *speaker,
+                                    int B, int Tc, int Ts, float *logits, void *stream) {
+    VQ_REQUIRE(v && x && idx && speaker && logits, "vqcpc_vocoder_logits: null argument");
+    VQ_REQUIRE(B > 0 && Tc > 0 && Ts > 0 && Ts <= 2 * v->d.upsample_t * Tc,
+               "vocoder.forward: Ts=%d must be in (0, %d]", Ts, 2 * v->d.upsample_t * Tc);
+    VQ_REQUIRE(((uintptr_t)logits & 15) == 0, "vocoder.forward: logits must be 16-byte aligned");
+    return run_ar(v, idx, speaker, B, Tc, nullptr, x, Ts, 0, 0, nullptr, nullptr, logits, 0, (hipStream_t)stream);
+}
+
+extern "C" int vqcpc_vocoder_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc,
+                                       float *cond, void *stream) {
+    VQ_REQUIRE(v && idx && speaker && cond && B > 0 && Tc > 0, "vqcpc_vocoder_condition: bad argument");
+    return run_condition(v, idx, speaker, B, Tc, nullptr, cond, (hipStream_t)stream);
+}

@@ -1,0 +1,186 @@
+"""Drop-in ``Encoder`` / ``VQEmbeddingEMA`` for the reference's ``model.py`` (inference path).
+
+Same constructor (``Encoder(conf: ConfEncoder)``, ``model.py:17-34``), same
+``state_dict()`` key set (``model.py:43-57``), same ``encode`` / ``forward`` signatures
+(``model.py:59-86``).  The torch sub-modules below only HOLD the parameters (so
+``load_state_dict(checkpoint["encoder"])``, ``.to(device)``, ``.eval()`` and the
+``encoder.encoder[-1]`` forward hook of ``encode.py:34-40`` keep working); all arithmetic
+runs in ``libvqcpc_hip.so`` through the C ABI of ``include/vqcpc.h``.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from itertools import chain
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+
+MISSING = "???"   # stands where the reference uses omegaconf.MISSING (model.py:6)
+
+
+@dataclass
+class ConfEncoder:
+    """``model.py:17-31``."""
+    in_channels: int = MISSING
+    channels: int = MISSING
+    n_embeddings: int = MISSING
+    z_dim: int = MISSING
+    c_dim: int = MISSING
+
+
+class VQEmbeddingEMA(nn.Module):
+    """Buffer holder for the codebook (``model.py:89-101``).
+
+    ``encode`` / eval-mode ``forward`` (``model.py:103-155``) are served by the owning
+    ``Encoder`` (the VQ search is fused behind ``vqcpc_encoder_encode``); the EMA update of
+    training mode (``model.py:136-145``) is outside the inference path.
+    """
+
+    def __init__(self, n_embeddings, embedding_dim, commitment_cost=0.25, decay=0.999, epsilon=1e-5):
+        super().__init__()
+        self.commitment_cost, self.decay, self.epsilon = commitment_cost, decay, epsilon
+        init_bound = 1 / 512
+        embedding = torch.empty(n_embeddings, embedding_dim).uniform_(-init_bound, init_bound)
+        self.register_buffer("embedding", embedding)
+        self.register_buffer("ema_count", torch.zeros(n_embeddings))
+        self.register_buffer("ema_weight", self.embedding.clone())
+
+
+class Encoder(nn.Module):
+    """Spec-Conv1d/k4s2-LN-ReLU-[FC-LN-ReLU]x4-FC-VQ + LSTM (``model.py:33-86``) on MI355X."""
+
+    def __init__(self, conf: ConfEncoder):
+        super().__init__()
+        self.conf = conf
+        self.conv = nn.Conv1d(conf.in_channels, conf.channels, 4, 2, 1, bias=False)
+        block = lambda: [nn.Linear(conf.channels, conf.channels, bias=False), nn.LayerNorm(conf.channels), nn.ReLU(True)]
+        self.encoder = nn.Sequential(nn.LayerNorm(conf.channels), nn.ReLU(True),
+                                     *chain.from_iterable(block() for _ in range(4)),
+                                     nn.Linear(conf.channels, conf.z_dim))
+        self.codebook = VQEmbeddingEMA(conf.n_embeddings, conf.z_dim)
+        self.rnn = nn.LSTM(conf.z_dim, conf.c_dim, batch_first=True)
+        self._handle = None
+        self._handle_key = None
+
+    # ------------------------------------------------------------------ native handle
+    def _weights(self):
+        sd = {k: v for k, v in self.state_dict().items()}
+        return [sd[k] for k in sd if k not in ("codebook.ema_count", "codebook.ema_weight")]
+
+    def _native(self):
+        ws = self._weights()
+        for w in ws:
+            _lib.require_cuda(w, "Encoder parameter")
+            if w.dtype != torch.float32:
+                raise RuntimeError("Encoder: parameters must be float32")
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (ws[0].device.index,)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._release()
+        sd = self.state_dict()
+        keep = []
+
+        def p(name):
+            t = sd[name].detach().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        w = _lib.EncoderWeights()
+        w.conv_weight = p("conv.weight")
+        for i, n in enumerate((0, 3, 6, 9, 12)):
+            w.ln_weight[i], w.ln_bias[i] = p(f"encoder.{n}.weight"), p(f"encoder.{n}.bias")
+        for i, n in enumerate((2, 5, 8, 11)):
+            w.fc_weight[i] = p(f"encoder.{n}.weight")
+        w.out_weight, w.out_bias = p("encoder.14.weight"), p("encoder.14.bias")
+        w.codebook = p("codebook.embedding")
+        w.rnn_w_ih, w.rnn_w_hh = p("rnn.weight_ih_l0"), p("rnn.weight_hh_l0")
+        w.rnn_b_ih, w.rnn_b_hh = p("rnn.bias_ih_l0"), p("rnn.bias_hh_l0")
+        c = self.conf
+        w.in_channels, w.channels, w.n_embeddings, w.z_dim, w.c_dim = (
+            c.in_channels, c.channels, c.n_embeddings, c.z_dim, c.c_dim)
+        h = C.c_void_p()
+        with torch.cuda.device(ws[0].device):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(_lib.load().vqcpc_encoder_create(C.byref(w), C.byref(h)))
+        self._handle, self._handle_key = h, key
+        return h
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.load().vqcpc_encoder_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference surface
+    def _encode_native(self, mel: Tensor, want_c: bool, conv_mode: int = 0):
+        _lib.require_cuda(mel, "mel")
+        if mel.dim() != 3 or mel.size(1) != self.conf.in_channels:
+            raise RuntimeError(f"expected mel of shape (B, {self.conf.in_channels}, T), got {tuple(mel.shape)}")
+        if mel.size(2) % 2 != 0:
+            mel = mel[:, :, : mel.size(2) - 1]       # Conv1d(k4,s2,p1) ignores a trailing odd frame (model.py:43)
+        mel = mel.detach().to(torch.float32).contiguous()
+        B, _, T = mel.shape
+        h = self._native()
+        dev = mel.device
+        z = torch.empty(B, T // 2, self.conf.z_dim, device=dev)
+        z_pre = torch.empty_like(z)
+        idx = torch.empty(B, T // 2, dtype=torch.int64, device=dev)
+        c = torch.empty(B, T // 2, self.conf.c_dim, device=dev) if want_c else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().vqcpc_encoder_encode(
+                h, mel.data_ptr(), B, T, conv_mode, z.data_ptr(), c.data_ptr() if want_c else None,
+                idx.data_ptr(), z_pre.data_ptr(), _lib.current_stream()))
+        last = self.encoder[-1]
+        for hook in list(last._forward_hooks.values()):     # encode.py:34-40 captures the pre-VQ activations
+            hook(last, (None,), z_pre)
+        return z, c, idx, z_pre
+
+    @torch.no_grad()
+    def encode(self, mel: Tensor, conv_mode: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
+        """``model.py:59-70``: (z, c, indices).  ``conv_mode``: see ``vqcpc.h`` (0 = as the reference)."""
+        z, c, idx, _ = self._encode_native(mel, want_c=True, conv_mode=conv_mode)
+        return z, c, idx
+
+    @torch.no_grad()
+    def encode_indices(self, mel: Tensor, conv_mode: int = 0) -> Tensor:
+        """What ``convert.py:76`` keeps of ``encode``: the code indices (LSTM skipped)."""
+        return self._encode_native(mel, want_c=False, conv_mode=conv_mode)[2]
+
+    @torch.no_grad()
+    def stage(self, mel: Tensor, stage: int, conv_mode: int = 0) -> Tensor:
+        """Activations after one front-end stage (``vqcpc_encoder_stage``), rows (B, T/2, F)."""
+        _lib.require_cuda(mel, "mel")
+        mel = mel.detach().to(torch.float32).contiguous()
+        B, _, T = mel.shape
+        F = self.conf.z_dim if stage == 10 else self.conf.channels
+        out = torch.empty(B, T // 2, F, device=mel.device)
+        with torch.cuda.device(mel.device):
+            _lib.check(_lib.load().vqcpc_encoder_stage(self._native(), mel.data_ptr(), B, T, conv_mode, stage,
+                                                       out.data_ptr(), _lib.current_stream()))
+        return out
+
+    def forward(self, mels: Tensor):
+        """``model.py:72-86`` in eval mode: (z, c, vq_loss, perplexity)."""
+        if self.training:
+            raise NotImplementedError("vectorquantizedcpc_amd.Encoder implements the inference path; "
+                                      "call .eval() (the EMA/straight-through training branch, model.py:136-145, is out of scope)")
+        with torch.no_grad():
+            zq, _, idx, z_pre = self._encode_native(mels, want_c=False)
+            B, Tz, D = zq.shape
+            z_st = torch.empty_like(zq)
+            stats = torch.empty(2, device=zq.device)
+            c = torch.empty(B, Tz, self.conf.c_dim, device=zq.device)
+            lib, h, s = _lib.load(), self._native(), _lib.current_stream()
+            with torch.cuda.device(zq.device):
+                _lib.check(lib.vqcpc_encoder_forward_stats(h, z_pre.data_ptr(), zq.data_ptr(), idx.data_ptr(), B * Tz,
+                                                           z_st.data_ptr(), stats[0:].data_ptr(), stats[1:].data_ptr(), s))
+                _lib.check(lib.vqcpc_encoder_context(h, z_st.data_ptr(), B, Tz, c.data_ptr(), s))
+        return z_st, c, stats[0], stats[1]
