@@ -1,0 +1,86 @@
+"""Utterance sharding across the GPUs of one node.
+
+Utterances are independent (the reference itself loops over them one by one,
+``encode.py:42`` / ``convert.py:52``), so the path shards with NO data-path collective:
+every rank (one process per GPU) holds replicated weights, encodes and decodes its own
+utterances, and ONE exchange at the end collects the waveforms on rank 0 -- a gather over
+RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo" in the CPU tests).
+"""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def partition_lpt(lengths: Sequence[int], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of utterance ids to ranks (decode cost is
+    proportional to the sample count).  Deterministic: ties broken by utterance id / rank id."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world_size
+    parts: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        parts[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(p) for p in parts]
+
+
+def partition_contiguous(n: int, world_size: int) -> List[List[int]]:
+    """Equal contiguous blocks (the weak-scaling bench: utterances of equal length)."""
+    per = (n + world_size - 1) // world_size
+    return [list(range(r * per, min(n, (r + 1) * per))) for r in range(world_size)]
+
+
+def gather_waveforms(wav: torch.Tensor, ids: Sequence[int], lengths: Sequence[int], n_total: int,
+                     dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+    """Collect per-rank waveforms on ``dst``.
+
+    wav: (n_local, L_local) this rank's padded waveforms, row k belongs to utterance ids[k] and
+    has lengths[k] valid samples.  Returns, on ``dst`` only, a list of n_total 1-D tensors in
+    utterance order.  Message plan: one all_gather of (count, L) per rank, then one gather of the
+    max-padded (count_max, L_max + 2) blocks whose first two columns carry (id, length).
+    """
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [wav[ids.index(i), : lengths[ids.index(i)]] for i in range(n_total)] if len(ids) == n_total else None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = wav.device
+    meta = torch.tensor([wav.shape[0], wav.shape[1] if wav.dim() == 2 else 0], device=dev, dtype=torch.int64)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    cmax = int(max(m[0] for m in metas))
+    lmax = int(max(m[1] for m in metas))
+    block = torch.zeros(cmax, lmax + 2, device=dev, dtype=torch.float32)
+    n = wav.shape[0]
+    if n:
+        block[:n, 0] = torch.tensor([float(i) for i in ids], device=dev)
+        block[:n, 1] = torch.tensor([float(v) for v in lengths], device=dev)
+        block[:n, 2: 2 + wav.shape[1]] = wav
+        block[n:, 0] = -1.0
+    else:
+        block[:, 0] = -1.0
+    out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
+    dist.gather(block, out, dst=dst, group=group)
+    if rank != dst:
+        return None
+    result: List[Optional[torch.Tensor]] = [None] * n_total
+    for r in range(world):
+        for k in range(int(metas[r][0])):
+            i, ln = int(out[r][k, 0]), int(out[r][k, 1])
+            result[i] = out[r][k, 2: 2 + ln]
+    return result
+
+
+def convert_sharded(mels: Sequence[torch.Tensor], speakers: Sequence[int],
+                    decode_fn: Callable[[List[int], List[torch.Tensor], List[int]], torch.Tensor],
+                    samples_per_frame: int = 160, group=None, dst: int = 0):
+    """Batched ``convert.py:52-77`` over a node: LPT-shard, decode locally, gather on ``dst``.
+
+    decode_fn(ids, mels, speakers) -> (n_local, L) padded waveforms for this rank's utterances
+    (the HIP path: ``Encoder.encode_indices`` + ``Vocoder.generate``).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lengths = [int(m.shape[-1]) // 2 * 2 * samples_per_frame for m in mels]
+    mine = partition_lpt(lengths, world)[rank]
+    wav = decode_fn(mine, [mels[i] for i in mine], [speakers[i] for i in mine])
+    return gather_waveforms(wav, mine, [lengths[i] for i in mine], len(mels), dst=dst, group=group)
