@@ -144,10 +144,12 @@ void vqcpc_vocoder_destroy(vqcpc_vocoder *voc);
  * vocoder.py:74-76).  idx DEVICE (B, Tc) int64 code indices; speaker DEVICE (B) int64;
  * n_codes HOST (B) per-utterance valid code counts, or NULL = all Tc (ragged batches:
  * utterance b produces 2*upsample_t*n_codes[b] samples, the rest of its row is zero).
- * Sampling protocol (project spec; the reference draws from torch's global CPU RNG, which
- * no device kernel can share): sample t of utterance u uses the uniform
- * Philox4x32-10(counter=(t, utt_base+b, 0, 0), key=seed) word0 >> 8 * 2^-24 and the
- * inverse CDF of softmax(logits).  Outputs DEVICE: wav (B, L) fp32 in [-1, 1] with
+ * Sampling protocol (project spec).  The reference draws x_t ~ Categorical(softmax(l_t)) from
+ * torch's global CPU RNG, which ATen implements as an exponential race (argmax_k p_k / q_k,
+ * q_k ~ Exp(1)); no device kernel can share that RNG stream, so the algorithm is kept and the
+ * stream fixed: class k of sample t of utterance u = utt_base + b uses
+ * w = Philox4x32-10(counter = (t, u, k >> 2, 0), key = seed)[k & 3],
+ * g_k = -log(-log(((w >> 8) + 0.5) * 2^-24)), and x_t = first argmax_k (l_k + g_k).  Outputs DEVICE: wav (B, L) fp32 in [-1, 1] with
  * L = 2*upsample_t*Tc, mu-law decoded (preprocess.py:30-35); mulaw (B, L) int64 class
  * indices or NULL.  max_steps > 0 stops after that many samples (tests). */
 int vqcpc_vocoder_generate(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
@@ -169,10 +171,16 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay. */
 int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
 
-/* Device time, in milliseconds, of the decode loop's dominant kernel (the GRU step) over
- * the last generate() call, measured with HIP events on the launch stream, and the number
- * of launches it covers.  Valid after the stream has been synchronised. */
+/* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call
+ * (HIP events on the launch stream) and the number of samples per utterance it covers.
+ * Valid after the stream has been synchronised. */
 int vqcpc_vocoder_last_timing(vqcpc_vocoder *voc, float *loop_ms, int *n_steps);
+
+/* Average wall time, in microseconds, of `reps` back-to-back launches of each per-sample kernel
+ * of the decode loop on the state the last generate()/logits() call left (HIP events on
+ * `stream`; synchronises it).  out_us[3] = {GRU step, fc1, fc2 + draw}.  Each figure includes
+ * this chip's ~1.5 us dependent-launch boundary. */
+int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 
 #ifdef __cplusplus
 }

@@ -45,8 +45,9 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         _lib.orc_sumsq64.restype = C.c_float
-        _lib.orc_sample_uniform.restype = C.c_float
-        _lib.orc_sample_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        _lib.orc_sample_noise.restype = C.c_float
+        _lib.orc_sample_noise.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        _lib.orc_sample_from_logits.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.orc_mulaw_decode.restype = C.c_float
         _lib.orc_mulaw_decode.argtypes = [C.c_int, C.c_int]
     return _lib
@@ -195,19 +196,21 @@ def philox4x32_10(ctr, key):
     return tuple(int(v) for v in o)
 
 
-def sample_uniform(seed, utterance, t):
-    return np.float32(lib().orc_sample_uniform(seed, utterance, t))
+def sample_noise(seed, utterance, t, k):
+    """Gumbel noise of class k, sample t, utterance `utterance` (see orc_sample_noise)."""
+    return np.float32(lib().orc_sample_noise(int(seed), int(utterance), int(t), int(k)))
 
 
 def mulaw_decode(s, bits=8):
     return np.float32(lib().orc_mulaw_decode(int(s), int(bits)))
 
 
-def sample_from_logits(logits, u, probe=-1):
+def sample_from_logits(logits, seed, utterance, t):
+    """Gumbel-max draw -> (class, scores[n])."""
     lg = _f32(logits)
-    lo, hi = C.c_float(), C.c_float()
-    k = lib().orc_sample_from_logits(_p(lg), lg.size, C.c_float(float(u)), int(probe), C.byref(lo), C.byref(hi))
-    return int(k), np.float32(lo.value), np.float32(hi.value)
+    sc = np.empty(lg.size, np.float32)
+    k = lib().orc_sample_from_logits(_p(lg), lg.size, int(seed), int(utterance), int(t), _p(sc))
+    return int(k), sc
 
 
 def _voc_struct(sd, upsample=160, bits=8):

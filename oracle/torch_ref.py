@@ -5,7 +5,7 @@ check of the C oracle's vocoder spec and (b) as the timed ``cpu_baseline`` ("por
 
 Encoder: the reference's own operator sequence (``model.py:59-70``: conv1d, LayerNorm, ReLU,
 Linear, addmm + argmin + embedding, LSTM).  Vocoder: nn.GRU prenet + GRUCell loop + two
-Linear + the project's Philox / inverse-CDF draw (``rnnms`` is absent: parity unpinned).
+Linear + the project's Philox-keyed Gumbel-max draw (``rnnms`` is absent: parity unpinned).
 """
 import numpy as np
 import torch
@@ -36,6 +36,22 @@ def encoder_encode(sd, mel, want_c=True):
     return q, c, idx.view(z.shape[0], z.shape[1]), z
 
 
+def make_noise(B, n_steps, seed, utt_base=0, chunk=256):
+    """Gumbel noise (B, n_steps, 256) of the sampling protocol:
+    Philox(counter=(t, utt, k>>2, 0), key=seed)[k&3] -> ((w>>8)+0.5)*2^-24 -> -log(-log(u))."""
+    out = torch.empty(B, n_steps, 256)
+    for t0 in range(0, n_steps, chunk):
+        n = min(chunk, n_steps - t0)
+        ctr = np.zeros((B * n * 64, 4), np.uint32)
+        ctr[:, 0] = np.tile(np.repeat(np.arange(t0, t0 + n, dtype=np.uint32), 64), B)
+        ctr[:, 1] = np.repeat(np.arange(utt_base, utt_base + B, dtype=np.uint32), n * 64)
+        ctr[:, 2] = np.tile(np.arange(64, dtype=np.uint32), B * n)
+        w = synth.philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(B, n, 256)
+        uni = torch.from_numpy(((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0))
+        out[:, t0:t0 + n] = -torch.log(-torch.log(uni))
+    return out
+
+
 class TorchVocoder:
     def __init__(self, sd, upsample=160):
         self.sd = sd
@@ -59,18 +75,14 @@ class TorchVocoder:
         return cond
 
     @torch.no_grad()
-    def generate(self, z, spk, seed, utt_base=0, n_steps=None, inputs=None, want_logits=False):
+    def generate(self, z, spk, seed, utt_base=0, n_steps=None, inputs=None, want_logits=False, noise=None):
         sd = self.sd
         B = z.shape[0]
         cond = self.condition(z, spk)
         total = self.up * cond.shape[1]
         n_steps = total if n_steps is None else min(n_steps, total)
-        # uniforms of the sampling protocol: Philox(counter=(t, utt, 0, 0), key=seed) word 0
-        ctr = np.zeros((B * n_steps, 4), np.uint32)
-        ctr[:, 0] = np.tile(np.arange(n_steps, dtype=np.uint32), B)
-        ctr[:, 1] = np.repeat(np.arange(utt_base, utt_base + B, dtype=np.uint32), n_steps)
-        w0 = synth.philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))[:, 0]
-        uni = torch.from_numpy(((w0 >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(B, n_steps))
+        if noise is None:
+            noise = make_noise(B, n_steps, seed, utt_base)
         h = torch.zeros(B, self.hr)
         x = torch.full((B,), 128, dtype=torch.long)
         samples = torch.empty(B, n_steps, dtype=torch.long)
@@ -83,11 +95,7 @@ class TorchVocoder:
             h = self.cell(inp, h)
             o = F.linear(F.relu(F.linear(h, sd["rnnms.ar.fc1.weight"], sd["rnnms.ar.fc1.bias"])),
                          sd["rnnms.ar.fc2.weight"], sd["rnnms.ar.fc2.bias"])
-            e = torch.exp(o - o.max(dim=1, keepdim=True).values)
-            cs = torch.cumsum(e, dim=1)
-            thr = uni[:, t: t + 1] * cs[:, -1:]
-            over = cs > thr
-            x = torch.where(over.any(dim=1), over.float().argmax(dim=1), torch.full((B,), 255))
+            x = torch.argmax(o + noise[:, t], dim=1)       # exponential race, as ATen's Categorical.sample
             samples[:, t] = x
             if want_logits:
                 logits_all[:, t] = o

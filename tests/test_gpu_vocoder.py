@@ -4,9 +4,9 @@ PARITY UNPINNED for this half: the reference's arithmetic lives in the absent th
 `rnnms`; the oracle is this project's CPU statement of the same spec (self-oracle).
 Tolerances (fp32, different summation order than the oracle's serial chains):
   prenet conditioning and teacher-forced logits: 2e-5 absolute;
-  free-running samples: every GPU draw must be the oracle's inverse-CDF choice for the same
-  history up to a CDF slack of 4e-6 (rounding of the softmax / prefix sums); identical
-  sample sequences give identical waveforms (mu-law table is the oracle's, MSE 0 <= 1e-5).
+  free-running samples: every GPU draw must be the oracle's Gumbel-max choice for the same
+  history, or a class whose oracle score is within 2e-5 of the oracle's best (a rounding-level
+  tie); identical sample sequences give identical waveforms (MSE 0 <= 1e-5).
 """
 import os
 
@@ -71,9 +71,8 @@ def _check_free_run(voc, sd, z, spk, n_codes, seed, utt_base, steps):
                                     inputs=inputs, want_logits=True)
         exact = int((r["samples"] == s_gpu).sum())
         for t in np.nonzero(r["samples"] != s_gpu)[0]:
-            u = oracle.sample_uniform(seed, utt_base + b, int(t))
-            _, lo, hi = oracle.sample_from_logits(r["logits"][t], u, probe=int(s_gpu[t]))
-            assert lo - 4e-6 <= u <= hi + 4e-6, (b, int(t), float(u), float(lo), float(hi))
+            pick, sc = oracle.sample_from_logits(r["logits"][t], seed, utt_base + b, int(t))
+            assert sc[pick] - sc[int(s_gpu[t])] <= 2e-5, (b, int(t), float(sc[pick]), float(sc[int(s_gpu[t])]))
         want_wav = np.array([oracle.mulaw_decode(int(s)) for s in s_gpu], np.float32)
         assert np.array_equal(wav[b, :n], want_wav)
         assert not wav[b, n:].any() and not mu[b, n:].any()

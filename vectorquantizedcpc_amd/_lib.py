@@ -16,7 +16,7 @@ SYMBOLS = [
     "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage",
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
-    "vqcpc_vocoder_last_timing",
+    "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
 ]
 
 
@@ -74,6 +74,7 @@ def load():
     lib.vqcpc_vocoder_condition.argtypes = [vp, i64p, i64p, i32, i32, vp, vp]
     lib.vqcpc_vocoder_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.vqcpc_vocoder_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.vqcpc_vocoder_kernel_times.argtypes = [vp, i32, C.POINTER(C.c_float), vp]
     _lib = lib
     return lib
 

@@ -223,7 +223,13 @@ int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream
 }
 
 // ------------------------------------------------------------------------------------------
-// Autoregressive sample loop: GRU step -> fc1 -> (fc2 + softmax + inverse-CDF draw + mu-law).
+// Autoregressive sample loop.  Per sample t, three launches (each an all-gather boundary):
+//   ar_gru : x_{t-1} = argmax of the fc2 candidates; h_t = GRUCell(Gemb[x_{t-1}] + Gcond, h_{t-1})
+//   ar_fc1 : a_t = relu(W1 h_t + b1)
+//   ar_fc2 : l_t = W2 a_t + b2; per 16-class row group the Gumbel-max candidate (score, class)
+// The categorical draw is an exponential race (argmax_k l_k + g_k, the algorithm of ATen's
+// Categorical.sample), which decomposes over class subsets: fc2 is spread over 16 CUs and the
+// 16 candidates per utterance are merged by the next step's GRU kernel.
 // Per-call quantities live in a device-side ArCall so one captured graph serves every call.
 // ------------------------------------------------------------------------------------------
 struct ArCall {
@@ -232,56 +238,131 @@ struct ArCall {
     float *wav;                // (B, Lout) or null
     int64_t *mulaw;            // (B, Lout) or null
     float *logits;             // (B, Ts, n_cls) or null
+    const int *len;            // [Bpad] samples per utterance
     int F, Ts, Lout, max_t, nbt;
     unsigned long long seed;
     unsigned utt_base;
     int t_base;                // advanced on device after every graph replay
 };
 
-struct ArModel {               // constant per handle
+struct ArModel {               // constant per handle (baked into the captured graph)
     const float *Wf_hh, *b_hh, *Gemb;
     const float *Wf_fc1, *b_fc1, *Wf_fc2, *b_fc2, *mulaw_tab;
     float *hbuf;               // [2][nbt][Hr*16]
     float *a1;                 // [nbt][Hf*16]
-    int *xprev;                // [Bpad]
-    const int *len;            // [Bpad] samples per utterance
+    float *cand_s;             // [Bpad][16] best score of each 16-class row group
+    int *cand_k;               // [Bpad][16] its class
     int Hr, Hf, n_cls, upsample;
 };
 
+#define AR_CHUNK 2             // utterance tiles (of 16) processed per pass: loads of both in flight
+
+// first-argmax over the 16 row-group candidates of utterance bg (row groups are in class order)
+__device__ __forceinline__ int merge_candidates(const ArModel &m, int bg) {
+    const float4 *ps = (const float4 *)(m.cand_s + (size_t)bg * 16);
+    const int4 *pk = (const int4 *)(m.cand_k + (size_t)bg * 16);
+    float best = -INFINITY;
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 sv = ps[q];
+        const int4 kv = pk[q];
+        if (sv.x > best) { best = sv.x; k = kv.x; }
+        if (sv.y > best) { best = sv.y; k = kv.y; }
+        if (sv.z > best) { best = sv.z; k = kv.z; }
+        if (sv.w > best) { best = sv.w; k = kv.w; }
+    }
+    return k;
+}
+
+template <int SW>
+__device__ __forceinline__ void load_hfrag(const float *hL, int K, int bt, int wave, int lane, float4 (&hv)[SW]) {
+    const float4 *hp = (const float4 *)hL + ((size_t)bt * (K >> 2)) * 16 + (size_t)wave * SW * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < SW; ++s) hv[s] = hp[s * 64];
+}
+template <int SW>
+__device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 (&hv)[SW]) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv[s].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv[s].y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv[s].z, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv[s].w, a1, 0, 0, 0);
+    }
+    return a0 + a1;
+}
+
 template <int SW>
 __global__ __launch_bounds__(256) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
-    __shared__ float red[4][16][17];
-    __shared__ float gate[16][17];
+    __shared__ float red[AR_CHUNK][4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, Hr = m.Hr;
+    float4 wf[SW];
+    load_wfrag<SW>(m.Wf_hh, rg, 4, wave, lane, wf);           // independent of the call record
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
     if (t >= c.max_t) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, Hr = m.Hr;
     const size_t hsz = (size_t)c.nbt * Hr * 16;
     const float *hin = m.hbuf + (size_t)(t & 1) * hsz;
     float *hout = m.hbuf + (size_t)((t + 1) & 1) * hsz;
-    float4 wf[SW];
-    load_wfrag<SW>(m.Wf_hh, rg, 4, wave, lane, wf);
     const int frame = t / m.upsample;
-    for (int bt = 0; bt < c.nbt; ++bt) {
-        const f32x4 acc = mv16<SW>(wf, hin, Hr, bt, wave, lane);
-        const float v = reduce4(red, acc, wave, lane, tid);
-        gate[tid >> 4][tid & 15] = v;
-        __syncthreads();
-        if (tid < 64) {
-            const int u = tid >> 4, b = tid & 15, bg = bt * 16 + b;
-            if (t < m.len[bg]) {
-                int x = c.inputs ? (int)c.inputs[(size_t)bg * c.Ts + t] : (t == 0 ? m.n_cls / 2 : m.xprev[bg]);
+    const int u = (tid & 63) >> 4, b = tid & 15, unit = 4 * rg + u;
+
+    for (int bt0 = 0; bt0 < c.nbt; bt0 += AR_CHUNK) {
+        const int nb = c.nbt - bt0 < AR_CHUNK ? c.nbt - bt0 : AR_CHUNK;
+        // (1) state fragments of both tiles in flight
+        float4 hv[AR_CHUNK][SW];
+#pragma unroll
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) load_hfrag<SW>(hin, Hr, bt0 + q, wave, lane, hv[q]);
+        // (2) wave q prefetches everything the cell update of tile q needs (hidden under (1) and the MFMAs)
+        bool active = false;
+        float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
+        size_t hi = 0;
+        if (wave < nb) {
+            const int bg = (bt0 + wave) * 16 + b;
+            active = t < c.len[bg];
+            if (active) {
+                int x;
+                if (c.inputs) x = (int)c.inputs[(size_t)bg * c.Ts + t];
+                else if (t == 0) x = m.n_cls / 2;
+                else {
+                    x = merge_candidates(m, bg);
+                    if (rg == 0 && u == 0) {                    // emit sample t-1 (network_vocoder.py:78 output)
+                        if (c.wav) c.wav[(size_t)bg * c.Lout + t - 1] = m.mulaw_tab[x];
+                        if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + t - 1] = x;
+                    }
+                }
                 x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
-                const int unit = 4 * rg + u;
                 const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
                 const float *gc = c.Gcond + ((size_t)bg * c.F + frame) * 3 * Hr + unit;
                 const float *bh = m.b_hh + unit;
-                const size_t hi = hl_index(Hr, bg, unit);
-                const float r = sigmoidf_((ge[0] + gc[0]) + (gate[u][b] + bh[0]));
-                const float z = sigmoidf_((ge[Hr] + gc[Hr]) + (gate[4 + u][b] + bh[Hr]));
-                const float n = tanhf((ge[2 * Hr] + gc[2 * Hr]) + r * (gate[8 + u][b] + bh[2 * Hr]));
-                hout[hi] = (1.0f - z) * n + z * hin[hi];
+                hi = hl_index(Hr, bg, unit);
+                ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
+                gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
+                bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
+                hold = hin[hi];
             }
+        }
+        // (3) W_hh h for both tiles, K quarters reduced through LDS
+#pragma unroll
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) {
+                const f32x4 acc = mfma_frag<SW>(wf, hv[q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+            }
+        __syncthreads();
+        // (4) cell update (PyTorch GRUCell equations, gate order r, z, n)
+        if (active) {
+            const float gr = ((red[wave][0][u][b] + red[wave][1][u][b]) + red[wave][2][u][b]) + red[wave][3][u][b];
+            const float gz = ((red[wave][0][4 + u][b] + red[wave][1][4 + u][b]) + red[wave][2][4 + u][b]) + red[wave][3][4 + u][b];
+            const float gn = ((red[wave][0][8 + u][b] + red[wave][1][8 + u][b]) + red[wave][2][8 + u][b]) + red[wave][3][8 + u][b];
+            const float r = sigmoidf_((ge0 + gc0) + (gr + bh0));
+            const float z = sigmoidf_((ge1 + gc1) + (gz + bh1));
+            const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
+            hout[hi] = (1.0f - z) * n + z * hold;
         }
         __syncthreads();
     }
@@ -289,26 +370,45 @@ __global__ __launch_bounds__(256) void ar_gru_kernel(ArModel m, const ArCall *__
 
 template <int SW>
 __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
-    __shared__ float red[4][16][17];
+    __shared__ float red[AR_CHUNK][4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x;
+    float4 wf[SW];
+    load_wfrag<SW>(m.Wf_fc1, rg, 4, wave, lane, wf);
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
     if (t >= c.max_t) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x;
     const float *h = m.hbuf + (size_t)((t + 1) & 1) * c.nbt * m.Hr * 16;
-    float4 wf[SW];
-    load_wfrag<SW>(m.Wf_fc1, rg, 4, wave, lane, wf);
-    for (int bt = 0; bt < c.nbt; ++bt) {
-        const f32x4 acc = mv16<SW>(wf, h, m.Hr, bt, wave, lane);
-        float v = reduce4(red, acc, wave, lane, tid);
-        const int row = 16 * rg + (tid >> 4), bg = bt * 16 + (tid & 15);
-        v += m.b_fc1[row];
-        m.a1[hl_index(m.Hf, bg, row)] = v > 0.f ? v : 0.f;
+    const int row = 16 * rg + (tid >> 4);
+    const float bias = m.b_fc1[row];
+    for (int bt0 = 0; bt0 < c.nbt; bt0 += AR_CHUNK) {
+        const int nb = c.nbt - bt0 < AR_CHUNK ? c.nbt - bt0 : AR_CHUNK;
+        float4 hv[AR_CHUNK][SW];
+#pragma unroll
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) load_hfrag<SW>(h, m.Hr, bt0 + q, wave, lane, hv[q]);
+#pragma unroll
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) {
+                const f32x4 acc = mfma_frag<SW>(wf, hv[q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) {
+                const int rr = tid >> 4, bb = tid & 15;
+                float v = ((red[q][0][rr][bb] + red[q][1][rr][bb]) + red[q][2][rr][bb]) + red[q][3][rr][bb];
+                v += bias;
+                m.a1[hl_index(m.Hf, (bt0 + q) * 16 + bb, row)] = v > 0.f ? v : 0.f;
+            }
         __syncthreads();
     }
 }
 
-__device__ __forceinline__ unsigned philox_word0(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
-    unsigned c[4] = {c0, c1, 0u, 0u};
+// Philox4x32-10, word `k & 3` of counter (t, utt, k >> 2, 0): the sampling protocol's stream.
+__device__ __forceinline__ unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned k0, unsigned k1, int w) {
+    unsigned c[4] = {c0, c1, c2, 0u};
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
@@ -318,79 +418,84 @@ __device__ __forceinline__ unsigned philox_word0(unsigned c0, unsigned c1, unsig
         c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c[0];
+    return w == 0 ? c[0] : w == 1 ? c[1] : w == 2 ? c[2] : c[3];
 }
 
-// One workgroup per 16-utterance tile: 16 waves = the 16 row groups of fc2 (n_cls = 256),
-// then wave w draws the sample of utterance w.
-__global__ __launch_bounds__(1024) void ar_head_kernel(ArModel m, ArCall *__restrict__ cp, int t_local) {
-    __shared__ float4 a1s[1024];           // a1 tile, fragment order (Hf = 256: 16 super-steps x 64 lanes)
-    __shared__ float lg[16][260];
+// fc2 over one 16-class row group + its Gumbel-max candidate per utterance.  Hf = 256: SW = 4.
+__global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
+    __shared__ float red[AR_CHUNK][4][16][17];
+    __shared__ float sc[AR_CHUNK][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x;
+    float4 wf[4];
+    load_wfrag<4>(m.Wf_fc2, rg, 4, wave, lane, wf);
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
     if (t >= c.max_t) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bt = blockIdx.x;
-    const int NS = m.Hf / 16;              // 16
-    for (int i = tid; i < NS * 64; i += 1024) a1s[i] = ((const float4 *)m.a1)[(size_t)bt * NS * 64 + i];
-    float4 wf[16];
-    load_wfrag<16>(m.Wf_fc2, wave, 1, 0, lane, wf);
-    __syncthreads();
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr;
+    const float bias = m.b_fc2[cls];
+    for (int bt0 = 0; bt0 < c.nbt; bt0 += AR_CHUNK) {
+        const int nb = c.nbt - bt0 < AR_CHUNK ? c.nbt - bt0 : AR_CHUNK;
+        float4 hv[AR_CHUNK][4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const float4 hv = a1s[s * 64 + lane];
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv.x, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv.y, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv.z, a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv.w, a3, 0, 0, 0);
-    }
-    const f32x4 acc = (a0 + a1) + (a2 + a3);
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) load_hfrag<4>(m.a1, m.Hf, bt0 + q, wave, lane, hv[q]);
+        // noise of (class, utterance) while the loads fly
+        float g[AR_CHUNK];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * wave + (lane >> 4) * 4 + r;
-        lg[lane & 15][row] = acc[r] + m.b_fc2[row];
-    }
-    __syncthreads();
-
-    const int bg = bt * 16 + wave;
-    if (t >= m.len[bg]) return;                       // wave-uniform
-    float v[4], e[4];
+        for (int q = 0; q < AR_CHUNK; ++q) {
+            const unsigned utt = c.utt_base + (unsigned)((bt0 + q) * 16 + bb);
+            const unsigned w = philox_word((unsigned)t, utt, (unsigned)(cls >> 2), (unsigned)c.seed,
+                                           (unsigned)(c.seed >> 32), cls & 3);
+            const float uni = ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            g[q] = -logf(-logf(uni));
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = lg[wave][4 * lane + i];
-    if (c.logits) *(float4 *)(c.logits + ((size_t)bg * c.Ts + t) * 256 + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
-    float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) {
+                const f32x4 acc = mfma_frag<4>(wf, hv[q]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+            }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = expf(v[i] - mx);
-    const float p0 = e[0], p1 = p0 + e[1], p2 = p1 + e[2], p3 = p2 + e[3];
-    float incl = p3;
+        for (int q = 0; q < AR_CHUNK; ++q)
+            if (q < nb) {
+                const int bg = (bt0 + q) * 16 + bb;
+                float v = ((red[q][0][rr][bb] + red[q][1][rr][bb]) + red[q][2][rr][bb]) + red[q][3][rr][bb];
+                v += bias;
+                if (c.logits && t < c.len[bg]) c.logits[((size_t)bg * c.Ts + t) * m.n_cls + cls] = v;
+                sc[q][rr][bb] = v + g[q];
+            }
+        __syncthreads();
+        if (tid < 16 * nb) {
+            const int q = tid >> 4, bg = (bt0 + q) * 16 + bb;
+            if (t < c.len[bg]) {
+                float best = sc[q][0][bb];
+                int k = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
-    float excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 0.f;
-    const float total = __shfl(incl, 63);
-    const unsigned w0 = philox_word0((unsigned)t, c.utt_base + (unsigned)bg, (unsigned)c.seed, (unsigned)(c.seed >> 32));
-    const float uni = (float)(w0 >> 8) * (1.0f / 16777216.0f);
-    const float thr = uni * total;
-    const unsigned long long mask = __ballot(excl + p3 > thr);
-    int s = m.n_cls - 1;
-    if (mask) {
-        const int lf = __ffsll((unsigned long long)mask) - 1;
-        int mine = (excl + p0 > thr) ? 0 : (excl + p1 > thr) ? 1 : (excl + p2 > thr) ? 2 : 3;
-        s = 4 * lf + __shfl(mine, lf);
-    }
-    if (lane == 0) {
-        m.xprev[bg] = s;
-        if (c.wav) c.wav[(size_t)bg * c.Lout + t] = m.mulaw_tab[s];
-        if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + t] = s;
+                for (int r = 1; r < 16; ++r)
+                    if (sc[q][r][bb] > best) { best = sc[q][r][bb]; k = r; }
+                m.cand_s[(size_t)bg * 16 + rg] = best;
+                m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
+            }
+        }
+        __syncthreads();
     }
 }
 
 __global__ void ar_advance_kernel(ArCall *c, int n) { c->t_base += n; }
+
+// After the loop: the last sample of every utterance is still only a set of candidates.
+__global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp, int Bpad) {
+    const int bg = blockIdx.x * blockDim.x + threadIdx.x;
+    const ArCall c = *cp;
+    if (bg >= Bpad || c.inputs) return;
+    const int n = c.len[bg];
+    if (n <= 0) return;
+    const int x = merge_candidates(m, bg);
+    if (c.wav) c.wav[(size_t)bg * c.Lout + n - 1] = m.mulaw_tab[x];
+    if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + n - 1] = x;
+}
 
 // Vocoder glue (network_vocoder.py:73-77): series[b, t2, :dz] = code_emb[idx[b, t2/2]], [dz:] = spk_emb[spk[b]]
 __global__ void glue_kernel(const int64_t *__restrict__ idx, const int64_t *__restrict__ spk,
@@ -432,13 +537,16 @@ struct vqcpc_vocoder {
     float *Wf_hh = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
     float *mulaw_tab = nullptr;
     ArCall *call = nullptr;              // device
-    DevBuf series, gi, out0, cond, gcond, hseq, har, a1, xprev, len;
+    DevBuf series, gi, out0, cond, gcond, hseq, har, a1, cand_s, cand_k, len;
     int use_graph = 1, steps_per_graph = 160;
     std::map<int, hipGraphExec_t> graphs; // key: nbt
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_steps = 0;
     const void *baked[4] = {nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
+    ArCall last_call{};                  // host copies of the last decode call (kernel timing)
+    ArModel last_model{};
+    bool have_last = false;
 };
 
 static int dcopy(float **dst, const float *src, size_t n) {
@@ -455,7 +563,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
                      v->Wf_fc1, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (v->call) (void)hipFree(v->call);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->har, &v->a1, &v->xprev, &v->len};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->har, &v->a1, &v->cand_s, &v->cand_k, &v->len};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -593,7 +701,7 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     return VQCPC_OK;
 }
 
-static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, hipStream_t s) {
+static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int n, hipStream_t s) {
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
     for (int i = 0; i < n; ++i) {
@@ -605,7 +713,7 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, h
 #undef CASE
             default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
         }
-        hipLaunchKernelGGL(ar_head_kernel, dim3(nbt), dim3(1024), 0, s, m, v->call, i);
+        hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16), blk, 0, s, m, (const ArCall *)v->call, i);
     }
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, v->call, n);
     HIP_TRY(hipGetLastError());
@@ -649,53 +757,57 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     const size_t hsz = (size_t)nbt * Hr * 16 * sizeof(float);
     TRY(v->har.reserve(2 * hsz));
     TRY(v->a1.reserve((size_t)nbt * d.Hf * 16 * sizeof(float)));
-    TRY(v->xprev.reserve(Bp * sizeof(int)));
+    TRY(v->cand_s.reserve((size_t)Bp * 16 * sizeof(float)));
+    TRY(v->cand_k.reserve((size_t)Bp * 16 * sizeof(int)));
     HIP_TRY(hipMemsetAsync(v->har.p, 0, 2 * hsz, s));
-    HIP_TRY(hipMemsetAsync(v->xprev.p, 0, Bp * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(v->cand_s.p, 0, (size_t)Bp * 16 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(v->cand_k.p, 0, (size_t)Bp * 16 * sizeof(int), s));
     if (wav && (ragged || max_steps > 0)) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw && (ragged || max_steps > 0)) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
     ArCall c{};
     c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
-    c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.utt_base = utt_base; c.t_base = 0;
+    c.len = samples_dev; c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.utt_base = utt_base; c.t_base = 0;
     HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));     // c is a stack-lifetime host buffer
 
     ArModel m{};
     m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.b_fc1 = v->b_fc1;
     m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
-    m.hbuf = v->har.as<float>(); m.a1 = v->a1.as<float>(); m.xprev = v->xprev.as<int>(); m.len = samples_dev;
+    m.hbuf = v->har.as<float>(); m.a1 = v->a1.as<float>(); m.cand_s = v->cand_s.as<float>(); m.cand_k = v->cand_k.as<int>();
     m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
 
     const int S = v->steps_per_graph;
     HIP_TRY(hipEventRecord(v->ev0, s));
     if (v->use_graph) {
         // The graph bakes ArModel (buffer pointers): drop cached graphs if a workspace moved.
-        const void *now[4] = {v->har.p, v->a1.p, v->xprev.p, v->len.p};
+        const void *now[4] = {v->har.p, v->a1.p, v->cand_s.p, v->cand_k.p};
         if (memcmp(v->baked, now, sizeof now) != 0) {
             for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
             v->graphs.clear();
             memcpy(v->baked, now, sizeof now);
         }
-        auto it = v->graphs.find(nbt);
+        auto it = v->graphs.find(0);           // grids and baked arguments no longer depend on the batch
         if (it == v->graphs.end()) {
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = launch_ar_steps(v, m, nbt, S, v->cap_stream);
+            int rc = launch_ar_steps(v, m, S, v->cap_stream);
             hipError_t e = hipStreamEndCapture(v->cap_stream, &g);
             if (rc != VQCPC_OK) return rc;
             HIP_TRY(e);
             HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             HIP_TRY(hipGraphDestroy(g));
-            it = v->graphs.emplace(nbt, ge).first;
+            it = v->graphs.emplace(0, ge).first;
         }
         for (int t0 = 0; t0 < max_t; t0 += S) HIP_TRY(hipGraphLaunch(it->second, s));
     } else {
-        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, nbt, S, s));
+        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, S, s));
     }
+    hipLaunchKernelGGL(ar_finalize_kernel, dim3((Bp + 63) / 64), dim3(64), 0, s, m, (const ArCall *)v->call, Bp);
     HIP_TRY(hipEventRecord(v->ev1, s));
     v->last_steps = max_t;
+    v->last_call = c; v->last_model = m; v->have_last = true;
     return VQCPC_OK;
 }
 
@@ -715,6 +827,46 @@ extern "C" int vqcpc_vocoder_logits(vqcpc_vocoder *v, const int64_t *x, const in
                "vocoder.forward: Ts=%d must be in (0, %d]", Ts, 2 * v->d.upsample_t * Tc);
     VQ_REQUIRE(((uintptr_t)logits & 15) == 0, "vocoder.forward: logits must be 16-byte aligned");
     return run_ar(v, idx, speaker, B, Tc, nullptr, x, Ts, 0, 0, nullptr, nullptr, logits, 0, (hipStream_t)stream);
+}
+
+// Average wall time of `reps` back-to-back launches of each per-sample kernel (HIP events on
+// `stream`), on the state the last generate()/logits() call left behind.  Includes the ~1.5 us
+// dependent-launch boundary of this chip.  out_us = {ar_gru, ar_fc1, ar_fc2}.
+extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out_us, void *stream) {
+    VQ_REQUIRE(v && out_us && reps > 0, "vqcpc_vocoder_kernel_times: bad argument");
+    VQ_REQUIRE(v->have_last, "vqcpc_vocoder_kernel_times: call generate() or logits() first");
+    hipStream_t s = (hipStream_t)stream;
+    ArCall c = v->last_call;
+    c.t_base = 1;                        // a mid-utterance step (t = 1: candidates are merged, Gemb gathered)
+    c.wav = nullptr; c.mulaw = nullptr; c.logits = nullptr;
+    HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const ArModel m = v->last_model;
+    const int SW = v->d.Hr / 64;
+    const dim3 blk(256);
+    for (int which = 0; which < 3; ++which) {
+        for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
+            if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
+            const int n = pass == 0 ? 20 : reps;
+            for (int i = 0; i < n; ++i) {
+                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16), blk, 0, s, m, (const ArCall *)v->call, 0); continue; }
+                switch (SW) {
+#define CASE(k) case k: \
+                    if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k>), dim3(v->d.Hr / 4), blk, 0, s, m, (const ArCall *)v->call, 0); \
+                    else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16), blk, 0, s, m, (const ArCall *)v->call, 0); break;
+                    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+#undef CASE
+                    default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
+                }
+            }
+        }
+        HIP_TRY(hipEventRecord(v->ev1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, v->ev0, v->ev1));
+        out_us[which] = ms * 1e3f / (float)reps;
+    }
+    return VQCPC_OK;
 }
 
 extern "C" int vqcpc_vocoder_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc,

@@ -155,6 +155,12 @@ class Vocoder(nn.Module):
         _lib.check(_lib.load().vqcpc_vocoder_last_timing(self._native(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_times(self, reps: int = 1000):
+        """Average microseconds per launch of (GRU step, fc1, fc2 + draw): ``vqcpc_vocoder_kernel_times``."""
+        out = (C.c_float * 3)()
+        _lib.check(_lib.load().vqcpc_vocoder_kernel_times(self._native(), int(reps), out, _lib.current_stream()))
+        return tuple(float(v) for v in out)
+
     # ------------------------------------------------------------------ reference surface
     @staticmethod
     def _prep(z: Tensor, speaker: Tensor):
