@@ -255,22 +255,25 @@ struct ArModel {               // constant per handle (baked into the captured g
     int Hr, Hf, n_cls, upsample;
 };
 
-#define AR_CHUNK 2             // utterance tiles (of 16) processed per pass: loads of both in flight
-
-// first-argmax over the 16 row-group candidates of utterance bg (row groups are in class order)
-__device__ __forceinline__ int merge_candidates(const ArModel &m, int bg) {
+// The 16 row-group candidates of utterance bg (row groups are in class order): request, then
+// first-argmax.  Split so that the request can be issued before the fragment loads (vmcnt
+// retires in order: a wait for these then does not wait for the fragments behind them).
+struct Cand { float4 s[4]; int4 k[4]; };
+__device__ __forceinline__ void load_candidates(const ArModel &m, int bg, Cand &cd) {
     const float4 *ps = (const float4 *)(m.cand_s + (size_t)bg * 16);
     const int4 *pk = (const int4 *)(m.cand_k + (size_t)bg * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cd.s[q] = ps[q]; cd.k[q] = pk[q]; }
+}
+__device__ __forceinline__ int merge_candidates(const Cand &cd) {
     float best = -INFINITY;
     int k = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 sv = ps[q];
-        const int4 kv = pk[q];
-        if (sv.x > best) { best = sv.x; k = kv.x; }
-        if (sv.y > best) { best = sv.y; k = kv.y; }
-        if (sv.z > best) { best = sv.z; k = kv.z; }
-        if (sv.w > best) { best = sv.w; k = kv.w; }
+        if (cd.s[q].x > best) { best = cd.s[q].x; k = cd.k[q].x; }
+        if (cd.s[q].y > best) { best = cd.s[q].y; k = cd.k[q].y; }
+        if (cd.s[q].z > best) { best = cd.s[q].z; k = cd.k[q].z; }
+        if (cd.s[q].w > best) { best = cd.s[q].w; k = cd.k[q].w; }
     }
     return k;
 }
@@ -294,41 +297,61 @@ __device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 
     return a0 + a1;
 }
 
-template <int SW>
-__global__ __launch_bounds__(256) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
-    __shared__ float red[AR_CHUNK][4][16][17];
+// Scheduling notes (checked in the .s): hipcc otherwise sinks each fragment load down to its
+// MFMA (load 2, wait, 4 MFMA, ...), hoists the call-record load and the exit branch above
+// everything, and falls back to vmcnt(0) around divergent branches.  So: sched_barrier(0) pins
+// "all fragment loads first"; there is no early return (stores are predicated); the ping-pong
+// parity of the state buffers comes from the launch index (steps_per_graph is even, t_base a
+// multiple of it), so fragments are requested before the call record has arrived; and the GRU
+// kernel is WAVE-SPECIALISED: waves 0-3 run a branch-free load -> MFMA -> LDS stream over the
+// four K quarters, waves 4.. (one per utterance tile in flight) chase the dependent loads of the
+// cell update (candidates -> x -> Gemb row, Gcond, biases, old state) meanwhile.
+template <int SW, int NB>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
+__global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
+    __shared__ float red[NB][4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, Hr = m.Hr;
-    float4 wf[SW];
-    load_wfrag<SW>(m.Wf_hh, rg, 4, wave, lane, wf);           // independent of the call record
-    const ArCall c = *cp;
-    const int t = c.t_base + t_local;
-    if (t >= c.max_t) return;
-    const size_t hsz = (size_t)c.nbt * Hr * 16;
-    const float *hin = m.hbuf + (size_t)(t & 1) * hsz;
-    float *hout = m.hbuf + (size_t)((t + 1) & 1) * hsz;
-    const int frame = t / m.upsample;
-    const int u = (tid & 63) >> 4, b = tid & 15, unit = 4 * rg + u;
+    const size_t hsz = (size_t)nbt * Hr * 16;
+    const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
+    float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
+    const bool mfma_wave = wave < 4;                 // wave-uniform
+    const int g = wave - 4;                          // gate wave index = tile slot
+    const int u = lane >> 4, b = lane & 15, unit = 4 * rg + u;
 
-    for (int bt0 = 0; bt0 < c.nbt; bt0 += AR_CHUNK) {
-        const int nb = c.nbt - bt0 < AR_CHUNK ? c.nbt - bt0 : AR_CHUNK;
-        // (1) state fragments of both tiles in flight
-        float4 hv[AR_CHUNK][SW];
-#pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) load_hfrag<SW>(hin, Hr, bt0 + q, wave, lane, hv[q]);
-        // (2) wave q prefetches everything the cell update of tile q needs (hidden under (1) and the MFMAs)
+    float4 wf[SW];
+    if (mfma_wave) load_wfrag<SW>(m.Wf_hh, rg, 4, wave, lane, wf);
+
+    for (int bt0 = 0; bt0 < nbt; bt0 += NB) {
         bool active = false;
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
         size_t hi = 0;
-        if (wave < nb) {
-            const int bg = (bt0 + wave) * 16 + b;
-            active = t < c.len[bg];
+        if (mfma_wave) {
+            float4 hv[NB][SW];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int bt = bt0 + q < nbt ? bt0 + q : nbt - 1;        // clamped: no branch around loads
+                load_hfrag<SW>(hin, Hr, bt, wave, lane, hv[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const f32x4 acc = mfma_frag<SW>(wf, hv[q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+            }
+        } else {
+            const int bt = bt0 + g;
+            const int bg = (bt < nbt ? bt : nbt - 1) * 16 + b;
+            Cand cd;
+            load_candidates(m, bg, cd);
+            const ArCall c = *cp;
+            const int t = c.t_base + t_local;
+            active = bt < nbt && t < c.max_t && t < c.len[bg];
             if (active) {
                 int x;
                 if (c.inputs) x = (int)c.inputs[(size_t)bg * c.Ts + t];
                 else if (t == 0) x = m.n_cls / 2;
                 else {
-                    x = merge_candidates(m, bg);
+                    x = merge_candidates(cd);
                     if (rg == 0 && u == 0) {                    // emit sample t-1 (network_vocoder.py:78 output)
                         if (c.wav) c.wav[(size_t)bg * c.Lout + t - 1] = m.mulaw_tab[x];
                         if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + t - 1] = x;
@@ -336,7 +359,7 @@ __global__ __launch_bounds__(256) void ar_gru_kernel(ArModel m, const ArCall *__
                 }
                 x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
                 const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
-                const float *gc = c.Gcond + ((size_t)bg * c.F + frame) * 3 * Hr + unit;
+                const float *gc = c.Gcond + ((size_t)bg * c.F + t / m.upsample) * 3 * Hr + unit;
                 const float *bh = m.b_hh + unit;
                 hi = hl_index(Hr, bg, unit);
                 ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
@@ -345,65 +368,43 @@ __global__ __launch_bounds__(256) void ar_gru_kernel(ArModel m, const ArCall *__
                 hold = hin[hi];
             }
         }
-        // (3) W_hh h for both tiles, K quarters reduced through LDS
-#pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) {
-                const f32x4 acc = mfma_frag<SW>(wf, hv[q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-            }
         __syncthreads();
-        // (4) cell update (PyTorch GRUCell equations, gate order r, z, n)
+        // cell update (PyTorch GRUCell equations, gate order r, z, n), K quarters summed in fixed order
         if (active) {
-            const float gr = ((red[wave][0][u][b] + red[wave][1][u][b]) + red[wave][2][u][b]) + red[wave][3][u][b];
-            const float gz = ((red[wave][0][4 + u][b] + red[wave][1][4 + u][b]) + red[wave][2][4 + u][b]) + red[wave][3][4 + u][b];
-            const float gn = ((red[wave][0][8 + u][b] + red[wave][1][8 + u][b]) + red[wave][2][8 + u][b]) + red[wave][3][8 + u][b];
+            const float gr = ((red[g][0][u][b] + red[g][1][u][b]) + red[g][2][u][b]) + red[g][3][u][b];
+            const float gz = ((red[g][0][4 + u][b] + red[g][1][4 + u][b]) + red[g][2][4 + u][b]) + red[g][3][4 + u][b];
+            const float gn = ((red[g][0][8 + u][b] + red[g][1][8 + u][b]) + red[g][2][8 + u][b]) + red[g][3][8 + u][b];
             const float r = sigmoidf_((ge0 + gc0) + (gr + bh0));
             const float z = sigmoidf_((ge1 + gc1) + (gz + bh1));
             const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
             hout[hi] = (1.0f - z) * n + z * hold;
         }
-        __syncthreads();
+        if (bt0 + NB < nbt) __syncthreads();
     }
 }
 
+// fc1 / fc2: grid = (row groups, utterance tiles) -- at most 16 x nbt workgroups.
 template <int SW>
-__global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
-    __shared__ float red[AR_CHUNK][4][16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x;
-    float4 wf[SW];
+__global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
+    __shared__ float red[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
+    const float *h = m.hbuf + (size_t)((t_local + 1) & 1) * nbt * m.Hr * 16;
+    float4 wf[SW], hv[SW];
     load_wfrag<SW>(m.Wf_fc1, rg, 4, wave, lane, wf);
-    const ArCall c = *cp;
-    const int t = c.t_base + t_local;
-    if (t >= c.max_t) return;
-    const float *h = m.hbuf + (size_t)((t + 1) & 1) * c.nbt * m.Hr * 16;
+    load_hfrag<SW>(h, m.Hr, bt, wave, lane, hv);
     const int row = 16 * rg + (tid >> 4);
     const float bias = m.b_fc1[row];
-    for (int bt0 = 0; bt0 < c.nbt; bt0 += AR_CHUNK) {
-        const int nb = c.nbt - bt0 < AR_CHUNK ? c.nbt - bt0 : AR_CHUNK;
-        float4 hv[AR_CHUNK][SW];
+    __builtin_amdgcn_sched_barrier(0);
+    const ArCall c = *cp;
+    const bool valid = c.t_base + t_local < c.max_t;
+    const f32x4 acc = mfma_frag<SW>(wf, hv);
 #pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) load_hfrag<SW>(h, m.Hr, bt0 + q, wave, lane, hv[q]);
-#pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) {
-                const f32x4 acc = mfma_frag<SW>(wf, hv[q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) {
-                const int rr = tid >> 4, bb = tid & 15;
-                float v = ((red[q][0][rr][bb] + red[q][1][rr][bb]) + red[q][2][rr][bb]) + red[q][3][rr][bb];
-                v += bias;
-                m.a1[hl_index(m.Hf, (bt0 + q) * 16 + bb, row)] = v > 0.f ? v : 0.f;
-            }
-        __syncthreads();
-    }
+    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    __syncthreads();
+    const int rr = tid >> 4, bb = tid & 15;
+    float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
+    v += bias;
+    if (valid) m.a1[hl_index(m.Hf, bt * 16 + bb, row)] = v > 0.f ? v : 0.f;
 }
 
 // Philox4x32-10, word `k & 3` of counter (t, utt, k >> 2, 0): the sampling protocol's stream.
@@ -423,63 +424,40 @@ __device__ __forceinline__ unsigned philox_word(unsigned c0, unsigned c1, unsign
 
 // fc2 over one 16-class row group + its Gumbel-max candidate per utterance.  Hf = 256: SW = 4.
 __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
-    __shared__ float red[AR_CHUNK][4][16][17];
-    __shared__ float sc[AR_CHUNK][16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x;
-    float4 wf[4];
+    __shared__ float red[4][16][17];
+    __shared__ float sc[16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
+    float4 wf[4], hv[4];
     load_wfrag<4>(m.Wf_fc2, rg, 4, wave, lane, wf);
+    load_hfrag<4>(m.a1, m.Hf, bt, wave, lane, hv);
+    const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;
+    const float bias = m.b_fc2[cls];
+    __builtin_amdgcn_sched_barrier(0);
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
-    if (t >= c.max_t) return;
-    const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr;
-    const float bias = m.b_fc2[cls];
-    for (int bt0 = 0; bt0 < c.nbt; bt0 += AR_CHUNK) {
-        const int nb = c.nbt - bt0 < AR_CHUNK ? c.nbt - bt0 : AR_CHUNK;
-        float4 hv[AR_CHUNK][4];
+    // noise of (class, utterance) while the loads fly
+    const unsigned w = philox_word((unsigned)t, c.utt_base + (unsigned)bg, (unsigned)(cls >> 2), (unsigned)c.seed,
+                                   (unsigned)(c.seed >> 32), cls & 3);
+    const float g = -logf(-logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f)));
+    const bool live = t < c.max_t && t < c.len[bg];
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 acc = mfma_frag<4>(wf, hv);
 #pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) load_hfrag<4>(m.a1, m.Hf, bt0 + q, wave, lane, hv[q]);
-        // noise of (class, utterance) while the loads fly
-        float g[AR_CHUNK];
+    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    __syncthreads();
+    float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
+    v += bias;
+    if (c.logits && live) c.logits[((size_t)bg * c.Ts + t) * m.n_cls + cls] = v;
+    sc[rr][bb] = v + g;
+    __syncthreads();
+    if (tid < 16 && live) {
+        float best = sc[0][bb];
+        int k = 0;
 #pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q) {
-            const unsigned utt = c.utt_base + (unsigned)((bt0 + q) * 16 + bb);
-            const unsigned w = philox_word((unsigned)t, utt, (unsigned)(cls >> 2), (unsigned)c.seed,
-                                           (unsigned)(c.seed >> 32), cls & 3);
-            const float uni = ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
-            g[q] = -logf(-logf(uni));
-        }
-#pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) {
-                const f32x4 acc = mfma_frag<4>(wf, hv[q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < AR_CHUNK; ++q)
-            if (q < nb) {
-                const int bg = (bt0 + q) * 16 + bb;
-                float v = ((red[q][0][rr][bb] + red[q][1][rr][bb]) + red[q][2][rr][bb]) + red[q][3][rr][bb];
-                v += bias;
-                if (c.logits && t < c.len[bg]) c.logits[((size_t)bg * c.Ts + t) * m.n_cls + cls] = v;
-                sc[q][rr][bb] = v + g[q];
-            }
-        __syncthreads();
-        if (tid < 16 * nb) {
-            const int q = tid >> 4, bg = (bt0 + q) * 16 + bb;
-            if (t < c.len[bg]) {
-                float best = sc[q][0][bb];
-                int k = 0;
-#pragma unroll
-                for (int r = 1; r < 16; ++r)
-                    if (sc[q][r][bb] > best) { best = sc[q][r][bb]; k = r; }
-                m.cand_s[(size_t)bg * 16 + rg] = best;
-                m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
-            }
-        }
-        __syncthreads();
+        for (int r = 1; r < 16; ++r)
+            if (sc[r][bb] > best) { best = sc[r][bb]; k = r; }
+        m.cand_s[(size_t)bg * 16 + rg] = best;
+        m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
     }
 }
 
@@ -492,7 +470,9 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp, int
     if (bg >= Bpad || c.inputs) return;
     const int n = c.len[bg];
     if (n <= 0) return;
-    const int x = merge_candidates(m, bg);
+    Cand cd;
+    load_candidates(m, bg, cd);
+    const int x = merge_candidates(cd);
     if (c.wav) c.wav[(size_t)bg * c.Lout + n - 1] = m.mulaw_tab[x];
     if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + n - 1] = x;
 }
@@ -652,7 +632,7 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
     VQ_REQUIRE(v && name, "vqcpc_vocoder_set_option: null argument");
     if (!strcmp(name, "use_graph")) { v->use_graph = value != 0; return VQCPC_OK; }
     if (!strcmp(name, "steps_per_graph")) {
-        VQ_REQUIRE(value > 0 && value <= 4096, "steps_per_graph out of range");
+        VQ_REQUIRE(value > 0 && value <= 4096 && value % 2 == 0, "steps_per_graph must be even and in [2, 4096]");
         if (value != v->steps_per_graph) {
             for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
             v->graphs.clear();
@@ -701,19 +681,20 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     return VQCPC_OK;
 }
 
-static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int n, hipStream_t s) {
+static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, hipStream_t s) {
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
     for (int i = 0; i < n; ++i) {
         switch (SW) {
 #define CASE(k) case k: \
-            hipLaunchKernelGGL((ar_gru_kernel<k>), dim3(v->d.Hr / 4), blk, 0, s, m, (const ArCall *)v->call, i); \
-            hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16), blk, 0, s, m, (const ArCall *)v->call, i); break;
+            if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, i, nbt); \
+            else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4), dim3(384), 0, s, m, (const ArCall *)v->call, i, nbt); \
+            hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i, nbt); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
             default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
         }
-        hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16), blk, 0, s, m, (const ArCall *)v->call, i);
+        hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i);
     }
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, v->call, n);
     HIP_TRY(hipGetLastError());
@@ -787,22 +768,22 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
             v->graphs.clear();
             memcpy(v->baked, now, sizeof now);
         }
-        auto it = v->graphs.find(0);           // grids and baked arguments no longer depend on the batch
+        auto it = v->graphs.find(nbt);
         if (it == v->graphs.end()) {
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = launch_ar_steps(v, m, S, v->cap_stream);
+            int rc = launch_ar_steps(v, m, nbt, S, v->cap_stream);
             hipError_t e = hipStreamEndCapture(v->cap_stream, &g);
             if (rc != VQCPC_OK) return rc;
             HIP_TRY(e);
             HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             HIP_TRY(hipGraphDestroy(g));
-            it = v->graphs.emplace(0, ge).first;
+            it = v->graphs.emplace(nbt, ge).first;
         }
         for (int t0 = 0; t0 < max_t; t0 += S) HIP_TRY(hipGraphLaunch(it->second, s));
     } else {
-        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, S, s));
+        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, nbt, S, s));
     }
     hipLaunchKernelGGL(ar_finalize_kernel, dim3((Bp + 63) / 64), dim3(64), 0, s, m, (const ArCall *)v->call, Bp);
     HIP_TRY(hipEventRecord(v->ev1, s));
@@ -849,11 +830,12 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
             if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
             const int n = pass == 0 ? 20 : reps;
             for (int i = 0; i < n; ++i) {
-                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16), blk, 0, s, m, (const ArCall *)v->call, 0); continue; }
+                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)v->call, 0); continue; }
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k>), dim3(v->d.Hr / 4), blk, 0, s, m, (const ArCall *)v->call, 0); \
-                    else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16), blk, 0, s, m, (const ArCall *)v->call, 0); break;
+                    if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
+                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4), dim3(384), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
+                    else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)v->call, 0, c.nbt); break;
                     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
                     default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
