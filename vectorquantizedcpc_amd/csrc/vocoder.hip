@@ -317,19 +317,29 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
     const int g = wave - 4;                          // gate wave index = tile slot
     const int u = lane >> 4, b = lane & 15, unit = 4 * rg + u;
 
-    float4 wf[SW];
-    if (mfma_wave) load_wfrag<SW>(m.Wf_hh, rg, 4, wave, lane, wf);
-
-    for (int bt0 = 0; bt0 < nbt; bt0 += NB) {
+    // one pass of NB tiles per workgroup: grid.y = passes, so co-resident workgroups overlap one
+    // pass's fragment loads with another's MFMAs when many utterances are in flight
+    {
+        const int bt0 = blockIdx.y * NB;
         bool active = false;
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
         size_t hi = 0;
         if (mfma_wave) {
-            float4 hv[NB][SW];
+            // request order = consumption order (super-step s of the weights, then of every tile):
+            // the first MFMAs start while the tail of the fragments is still in flight
+            float4 wf[SW], hv[NB][SW];
+            const float4 *wp = (const float4 *)m.Wf_hh + ((size_t)(rg * 4 + wave) * SW) * 64 + lane;
+            const float4 *hp[NB];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int bt = bt0 + q < nbt ? bt0 + q : nbt - 1;        // clamped: no branch around loads
-                load_hfrag<SW>(hin, Hr, bt, wave, lane, hv[q]);
+                hp[q] = (const float4 *)hin + ((size_t)bt * (Hr >> 2)) * 16 + (size_t)wave * SW * 64 + lane;
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                wf[s] = wp[s * 64];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) hv[q][s] = hp[q][s * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -379,7 +389,6 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
             hout[hi] = (1.0f - z) * n + z * hold;
         }
-        if (bt0 + NB < nbt) __syncthreads();
     }
 }
 
@@ -688,7 +697,7 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, h
         switch (SW) {
 #define CASE(k) case k: \
             if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, i, nbt); \
-            else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4), dim3(384), 0, s, m, (const ArCall *)v->call, i, nbt); \
+            else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)v->call, i, nbt); \
             hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i, nbt); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
@@ -834,7 +843,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                 switch (SW) {
 #define CASE(k) case k: \
                     if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
-                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4), dim3(384), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
+                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
                     else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)v->call, 0, c.nbt); break;
                     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
