@@ -142,6 +142,8 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
 
     enc, voc = build_models(dev)
+    if os.environ.get("VQCPC_BENCH_NO_GRAPH"):           # counter collection (rocprofv3 --pmc) needs plain launches
+        voc.set_option("use_graph", 0)
     Bp, T = args.utterances_per_gpu, args.frames
     n_total = Bp * world
     ids = shard.partition_contiguous(n_total, world)[rank]

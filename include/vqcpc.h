@@ -82,10 +82,11 @@ void vqcpc_encoder_destroy(vqcpc_encoder *enc);
 #define VQCPC_CONV_DIRECT 2
 
 /* Replaces Encoder.encode (model.py:59-70; callers encode.py:46, convert.py:76,
- * vocoder.py:59).  mel DEVICE (B, in_channels, T), T even.  Outputs DEVICE:
- * z_q (B, T/2, z_dim) quantised vectors; idx (B, T/2) int64 code indices;
- * c (B, T/2, c_dim) LSTM context or NULL to skip the LSTM (convert.py:76 discards it);
- * z_pre (B, T/2, z_dim) pre-VQ activations (the encode.py:34-40 hook) or NULL.
+ * vocoder.py:59).  mel DEVICE (B, in_channels, T), T >= 2; To = (T - 2) / 2 + 1 output frames
+ * (= T/2 for even T; an odd T keeps its last frame, as Conv1d(k=4, s=2, p=1) does).  Outputs
+ * DEVICE: z_q (B, To, z_dim) quantised vectors; idx (B, To) int64 code indices;
+ * c (B, To, c_dim) LSTM context or NULL to skip the LSTM (convert.py:76 discards it);
+ * z_pre (B, To, z_dim) pre-VQ activations (the encode.py:34-40 hook) or NULL.
  * Code indices are bit-identical to the reference's PyTorch-CPU path for calls with
  * >= 16 output frames ("Bit-exactness contract"). */
 int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
@@ -95,7 +96,7 @@ int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int
  * of a forward hook on the reference's modules (encode.py:34-40 hooks encoder.encoder[-1]):
  * stage 0 = conv output transposed to rows (model.py:65-67), 1 = encoder.0+1 (LN, ReLU),
  * 2+2l = encoder.{2,5,8,11}[l] (Linear), 3+2l = the LN+ReLU after it, 10 = encoder.14 (z_pre).
- * out DEVICE (B*T/2, channels) fp32, or (B*T/2, z_dim) for stage 10. */
+ * out DEVICE (B*To, channels) fp32, or (B*To, z_dim) for stage 10. */
 int vqcpc_encoder_stage(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
                         int stage, float *out, void *stream);
 
@@ -147,14 +148,16 @@ void vqcpc_vocoder_destroy(vqcpc_vocoder *voc);
  * Sampling protocol (project spec).  The reference draws x_t ~ Categorical(softmax(l_t)) from
  * torch's global CPU RNG, which ATen implements as an exponential race (argmax_k p_k / q_k,
  * q_k ~ Exp(1)); no device kernel can share that RNG stream, so the algorithm is kept and the
- * stream fixed: class k of sample t of utterance u = utt_base + b uses
+ * stream fixed: class k of sample t of utterance u (= utt_ids[b], HOST (B), or utt_base + b when
+ * utt_ids is NULL -- an utterance's stream does not depend on how utterances are batched) uses
  * w = Philox4x32-10(counter = (t, u, k >> 2, 0), key = seed)[k & 3],
  * g_k = -log(-log(((w >> 8) + 0.5) * 2^-24)), and x_t = first argmax_k (l_k + g_k).  Outputs DEVICE: wav (B, L) fp32 in [-1, 1] with
  * L = 2*upsample_t*Tc, mu-law decoded (preprocess.py:30-35); mulaw (B, L) int64 class
  * indices or NULL.  max_steps > 0 stops after that many samples (tests). */
 int vqcpc_vocoder_generate(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
                            int B, int Tc, const int *n_codes, uint64_t seed, uint32_t utt_base,
-                           float *wav, int64_t *mulaw, int max_steps, void *stream);
+                           const uint32_t *utt_ids, float *wav, int64_t *mulaw, int max_steps,
+                           void *stream);
 
 /* Replaces Vocoder.forward (network_vocoder.py:41-67; caller vocoder.py:62): teacher-forced
  * energies.  x DEVICE (B, Ts) int64 mu-law input samples, Ts <= 2*upsample_t*Tc;

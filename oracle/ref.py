@@ -75,7 +75,7 @@ def conv1d_k4s2(x, w, mode=0):
     x, w = _f32(x), _f32(w)
     B, Cc, T = x.shape
     O = w.shape[0]
-    y = np.empty((B, T // 2, O), np.float32)
+    y = np.empty((B, (T - 2) // 2 + 1, O), np.float32)
     rc = lib().orc_conv1d_k4s2(_p(x), B, Cc, T, _p(w), O, int(mode), _p(y))
     assert rc == 0
     return y
@@ -174,11 +174,12 @@ def encoder_encode(sd, mel, want_c=True, conv_mode=0):
     mel = _f32(mel)
     B, _, T = mel.shape
     w, keep = _enc_struct(sd)
-    N = B * (T // 2)
-    zp = np.empty((B, T // 2, w.z_dim), np.float32)
+    To = (T - 2) // 2 + 1
+    N = B * To
+    zp = np.empty((B, To, w.z_dim), np.float32)
     zq = np.empty_like(zp)
-    idx = np.empty((B, T // 2), np.int64)
-    c = np.empty((B, T // 2, w.c_dim), np.float32) if want_c else None
+    idx = np.empty((B, To), np.int64)
+    c = np.empty((B, To, w.c_dim), np.float32) if want_c else None
     db = np.empty(N, np.float32)
     ds = np.empty(N, np.float32)
     rc = lib().orc_encoder_encode(C.byref(w), _p(mel), B, T, int(conv_mode), _p(zp), _p(zq), _p(idx), _p(c), _p(db), _p(ds))

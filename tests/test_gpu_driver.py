@@ -1,0 +1,54 @@
+"""-m gpu: the batched, length-bucketed drivers return, per utterance, exactly what a batch-1 call
+on that utterance returns (the reference's encode.py / convert.py loops are batch-1)."""
+import pytest
+import torch
+
+import vectorquantizedcpc_amd as V
+from vectorquantizedcpc_amd import driver, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def models():
+    enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
+    enc.load_state_dict(synth.encoder_state_dict())
+    voc = V.Vocoder(V.ConfVocoder())
+    voc.load_state_dict(synth.vocoder_state_dict())
+    return enc.cuda().eval(), voc.cuda().eval()
+
+
+def test_bucketing_rules():
+    lengths = [40, 41, 300, 44, 256, 258, 36]
+    modes = [driver.batch1_conv_mode(80, t) for t in lengths]
+    assert modes == [1, 1, 2, 1, 1, 2, 1]
+    buckets = driver.make_buckets(lengths, modes, max_batch=3, max_pad_frac=0.25)
+    assert sorted(i for b in buckets for i in b) == list(range(7))
+    for b in buckets:
+        assert len(b) <= 3 and len({modes[i] for i in b}) == 1
+        hi = max(lengths[i] for i in b)
+        assert hi * len(b) - sum(lengths[i] for i in b) <= 0.25 * hi * len(b)
+    assert driver.out_frames(33) == 16 and driver.out_frames(32) == 16 and driver.out_frames(2) == 1
+
+
+def test_encode_utterances_equals_batch1_calls():
+    enc, _ = models()
+    Ts = [40, 33, 64, 300, 47, 258, 36]
+    mels = [synth.mel(f"drv/{i}", 1, t)[0] for i, t in enumerate(Ts)]
+    got = driver.encode_utterances(enc, mels, want_context=True, max_batch=4)
+    for i, m in enumerate(mels):
+        z, c, idx = enc.encode(m[None].cuda())                # what encode.py:44-46 does
+        assert torch.equal(got[i]["indices"], idx[0]) and torch.equal(got[i]["z"], z[0]), i
+        assert torch.allclose(got[i]["c"], c[0], atol=1e-6, rtol=0), i
+
+
+def test_convert_utterances_equals_batch1_calls():
+    enc, voc = models()
+    Ts = [6, 9, 4, 8]
+    mels = [synth.mel(f"cv/{i}", 1, t)[0] for i, t in enumerate(Ts)]
+    spk = [3, 50, 7, 101]
+    got = driver.convert_utterances(enc, voc, mels, spk, seed=13, max_batch=3, max_pad_frac=0.5)
+    for i, m in enumerate(mels):
+        idx = enc.encode_indices(m[None].cuda())
+        wav = voc.generate(idx, torch.tensor([spk[i]], device="cuda"), seed=13, utt_ids=[i])
+        assert got[i].shape == (320 * driver.out_frames(Ts[i]),)
+        assert torch.equal(got[i], wav[0]), i

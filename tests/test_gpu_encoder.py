@@ -17,7 +17,7 @@ import vectorquantizedcpc_amd as V
 from vectorquantizedcpc_amd import synth
 
 pytestmark = pytest.mark.gpu
-CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16"]
+CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16", "odd_2x33", "long_1x300"]
 
 
 def sha(a):
@@ -49,13 +49,13 @@ def load_case(name, golden_dir):
 def test_indices_bit_exact_vs_reference(name, golden_dir):
     g, enc, _, mel = load_case(name, golden_dir)
     z, c, idx = enc.encode(mel.cuda())
-    assert idx.dtype == torch.int64 and idx.shape == (mel.shape[0], mel.shape[2] // 2)
+    assert idx.dtype == torch.int64 and idx.shape == (mel.shape[0], (mel.shape[2] - 2) // 2 + 1)
     got = idx.cpu().numpy()
     want = g["indices"].astype(np.int64)
     bad = np.nonzero(got != want)
     margin = (g["d_second"] - g["d_best"]).reshape(want.shape)
     assert bad[0].size == 0, f"{bad[0].size} index mismatches; reference margins there: {margin[bad][:8]}"
-    assert z.shape == (mel.shape[0], mel.shape[2] // 2, 64) and c.shape[-1] == 256
+    assert z.shape == (mel.shape[0], (mel.shape[2] - 2) // 2 + 1, 64) and c.shape[-1] == 256
 
 
 @pytest.mark.parametrize("name", [c for c in CASES if c != "tiny_1x16"])
@@ -119,7 +119,7 @@ def test_hook_and_error_surface():
     assert len(seen) == 1 and seen[0].shape == (2, 20, 64)
     q = enc.codebook.embedding[idx]                      # F.embedding gather (model.py:113)
     assert torch.equal(q, z)
-    z2, _, idx2 = enc.encode(synth.mel("hook", 2, 41)[:, :, :41].cuda())   # odd T: last frame unused by k4s2p1
+    z2, _, idx2 = enc.encode(synth.mel("hook", 2, 41).cuda())   # odd T: floor((T-2)/2)+1 frames
     assert idx2.shape == (2, 20)
     with pytest.raises(RuntimeError):
         enc.encode(torch.zeros(1, 40, 32, device="cuda"))

@@ -15,7 +15,7 @@ import pytest
 import oracle
 from vectorquantizedcpc_amd import synth
 
-CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16"]
+CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16", "odd_2x33", "long_1x300"]
 _cache = {}
 
 

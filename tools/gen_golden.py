@@ -37,6 +37,8 @@ ENCODER_CASES = {
     "c2_random_data": (64, 128, "random", "data"),  # perturbed LN affine, data-scale codebook
     "ragged_3x32": (3, 32, "random", "init"),     # 48 rows, smallest MKL "large-M" regime
     "tiny_1x16": (1, 16, "init", "init"),         # 8 rows: reference takes MKL's small-M path
+    "odd_2x33": (2, 33, "random", "data"),        # odd T: floor((T-2)/2)+1 = 16 frames each, last frame used
+    "long_1x300": (1, 300, "init", "init"),       # B = 1 but 80*T > 20480: ATen switches to oneDNN
 }
 
 
@@ -95,7 +97,7 @@ def encoder_fixture(model, name, B, T, ln_affine, codebook):
         out[f"rows_{k}"] = a2[:: max(1, a2.shape[0] // 4)][:4].copy()   # 4 spread-out full rows
     np.savez_compressed(os.path.join(GOLD, f"encoder_{name}.npz"), **out)
     ulp = np.spacing(np.abs(out["d_best"]).astype(np.float32))
-    print(f"{name}: rows={B * T // 2} exact ties={out['n_exact_ties']} "
+    print(f"{name}: rows={B * ((T - 2) // 2 + 1)} exact ties={out['n_exact_ties']} "
           f"rows with margin<=4ulp={(out['d_second'] - out['d_best'] <= 4 * ulp).sum()} "
           f"loss={out['loss']:.6g} ppl={out['perplexity']:.6g}")
 

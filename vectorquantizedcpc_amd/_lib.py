@@ -69,7 +69,7 @@ def load():
     lib.vqcpc_vocoder_destroy.argtypes = [vp]
     lib.vqcpc_vocoder_destroy.restype = None
     lib.vqcpc_vocoder_generate.argtypes = [vp, i64p, i64p, i32, i32, C.POINTER(C.c_int), C.c_uint64, C.c_uint32,
-                                           vp, i64p, i32, vp]
+                                           C.POINTER(C.c_uint32), vp, i64p, i32, vp]
     lib.vqcpc_vocoder_logits.argtypes = [vp, i64p, i64p, i64p, i32, i32, i32, vp, vp]
     lib.vqcpc_vocoder_condition.argtypes = [vp, i64p, i64p, i32, i32, vp, vp]
     lib.vqcpc_vocoder_set_option.argtypes = [vp, C.c_char_p, i32]

@@ -458,7 +458,7 @@ extern "C" int vqcpc_encoder_create(const vqcpc_encoder_weights *w, vqcpc_encode
 // Returns the device buffer holding that stage's rows in *stage_out.
 static int encoder_front(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode, int stop_stage,
                          float *zp, const float **stage_out, hipStream_t s) {
-    const int C = e->in_channels, CH = e->channels, To = T / 2, N = B * To;
+    const int C = e->in_channels, CH = e->channels, To = (T - 2) / 2 + 1, N = B * To;
     if (conv_mode == VQCPC_CONV_AUTO)
         conv_mode = (B > 1 || (long)B * C * T > 20480) ? VQCPC_CONV_DIRECT : VQCPC_CONV_IM2COL;
     TRY(e->bufA.reserve((size_t)N * CH * sizeof(float)));
@@ -498,10 +498,10 @@ static int encoder_front(vqcpc_encoder *e, const float *mel, int B, int T, int c
 extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode,
                                     float *z_q, float *c, int64_t *idx, float *z_pre, void *stream) {
     VQ_REQUIRE(e && mel && z_q && idx, "vqcpc_encoder_encode: null argument");
-    VQ_REQUIRE(B > 0 && T >= 2 && T % 2 == 0, "encoder.encode: need B > 0 and even T >= 2 (got B=%d T=%d)", B, T);
+    VQ_REQUIRE(B > 0 && T >= 2, "encoder.encode: need B > 0 and T >= 2 (got B=%d T=%d)", B, T);
     VQ_REQUIRE(conv_mode >= 0 && conv_mode <= 2, "encoder.encode: conv_mode must be 0, 1 or 2");
     hipStream_t s = (hipStream_t)stream;
-    const int To = T / 2, N = B * To;
+    const int To = (T - 2) / 2 + 1, N = B * To;
     TRY(e->x2.reserve((size_t)N * sizeof(float)));
     const int npart = e->n_emb / 32;
     TRY(e->pd.reserve((size_t)N * npart * sizeof(float)));
@@ -528,9 +528,9 @@ extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, i
 extern "C" int vqcpc_encoder_stage(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode, int stage,
                                    float *out, void *stream) {
     VQ_REQUIRE(e && mel && out, "vqcpc_encoder_stage: null argument");
-    VQ_REQUIRE(B > 0 && T >= 2 && T % 2 == 0 && stage >= 0 && stage <= 10, "vqcpc_encoder_stage: bad shape or stage");
+    VQ_REQUIRE(B > 0 && T >= 2 && stage >= 0 && stage <= 10, "vqcpc_encoder_stage: bad shape or stage");
     hipStream_t s = (hipStream_t)stream;
-    const int N = B * (T / 2);
+    const int N = B * ((T - 2) / 2 + 1);
     const float *src = nullptr;
     float *zp = nullptr;
     if (stage == 10) {

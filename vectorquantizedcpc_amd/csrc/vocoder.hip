@@ -239,9 +239,9 @@ struct ArCall {
     int64_t *mulaw;            // (B, Lout) or null
     float *logits;             // (B, Ts, n_cls) or null
     const int *len;            // [Bpad] samples per utterance
+    const unsigned *utt;       // [Bpad] sampling-stream id of each utterance
     int F, Ts, Lout, max_t, nbt;
     unsigned long long seed;
-    unsigned utt_base;
     int t_base;                // advanced on device after every graph replay
 };
 
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
     // noise of (class, utterance) while the loads fly
-    const unsigned w = philox_word((unsigned)t, c.utt_base + (unsigned)bg, (unsigned)(cls >> 2), (unsigned)c.seed,
+    const unsigned w = philox_word((unsigned)t, c.utt[bg], (unsigned)(cls >> 2), (unsigned)c.seed,
                                    (unsigned)(c.seed >> 32), cls & 3);
     const float g = -logf(-logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f)));
     const bool live = t < c.max_t && t < c.len[bg];
@@ -712,13 +712,14 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, h
 
 // Shared driver of generate() and logits().
 static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int B, int Tc, const int *n_codes_host,
-                  const int64_t *inputs, int Ts, unsigned long long seed, unsigned utt_base, float *wav,
+                  const int64_t *inputs, int Ts, unsigned long long seed, unsigned utt_base,
+                  const uint32_t *utt_ids_host, float *wav,
                   int64_t *mulaw, float *logits, int max_steps, hipStream_t s) {
     const auto &d = v->d;
     const int Hr = d.Hr, dl = 2 * d.Hp, T2 = 2 * Tc, nbt = (B + 15) / 16, Bp = nbt * 16;
     const int Lout = d.upsample_t * T2;
     // per-utterance lengths: frames for the prenet, samples for the AR loop
-    std::vector<int> lens(2 * Bp, 0);
+    std::vector<int> lens(3 * Bp, 0);     // [frames | samples | sampling-stream ids]
     int max_t = 0;
     bool ragged = false;
     for (int b = 0; b < B; ++b) {
@@ -730,6 +731,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         if (inputs) ns = ns < Ts ? ns : Ts;
         if (max_steps > 0 && ns > max_steps) ns = max_steps;
         lens[Bp + b] = ns;
+        lens[2 * Bp + b] = (int)(utt_ids_host ? utt_ids_host[b] : utt_base + (unsigned)b);
         max_t = ns > max_t ? ns : max_t;
     }
     TRY(v->len.reserve(lens.size() * sizeof(int)));
@@ -757,7 +759,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
 
     ArCall c{};
     c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
-    c.len = samples_dev; c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.utt_base = utt_base; c.t_base = 0;
+    c.len = samples_dev; c.utt = (const unsigned *)(v->len.as<int>() + 2 * Bp); c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.t_base = 0;
     HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));     // c is a stack-lifetime host buffer
 
@@ -802,11 +804,11 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
 }
 
 extern "C" int vqcpc_vocoder_generate(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc,
-                                      const int *n_codes, uint64_t seed, uint32_t utt_base, float *wav,
-                                      int64_t *mulaw, int max_steps, void *stream) {
+                                      const int *n_codes, uint64_t seed, uint32_t utt_base, const uint32_t *utt_ids,
+                                      float *wav, int64_t *mulaw, int max_steps, void *stream) {
     VQ_REQUIRE(v && idx && speaker && wav, "vqcpc_vocoder_generate: null argument");
     VQ_REQUIRE(B > 0 && Tc > 0, "vocoder.generate: need B > 0 and Tc > 0 (got %d, %d)", B, Tc);
-    return run_ar(v, idx, speaker, B, Tc, n_codes, nullptr, 0, seed, utt_base, wav, mulaw, nullptr, max_steps,
+    return run_ar(v, idx, speaker, B, Tc, n_codes, nullptr, 0, seed, utt_base, utt_ids, wav, mulaw, nullptr, max_steps,
                   (hipStream_t)stream);
 }
 
@@ -816,7 +818,7 @@ extern "C" int vqcpc_vocoder_logits(vqcpc_vocoder *v, const int64_t *x, const in
     VQ_REQUIRE(B > 0 && Tc > 0 && Ts > 0 && Ts <= 2 * v->d.upsample_t * Tc,
                "vocoder.forward: Ts=%d must be in (0, %d]", Ts, 2 * v->d.upsample_t * Tc);
     VQ_REQUIRE(((uintptr_t)logits & 15) == 0, "vocoder.forward: logits must be 16-byte aligned");
-    return run_ar(v, idx, speaker, B, Tc, nullptr, x, Ts, 0, 0, nullptr, nullptr, logits, 0, (hipStream_t)stream);
+    return run_ar(v, idx, speaker, B, Tc, nullptr, x, Ts, 0, 0, nullptr, nullptr, nullptr, logits, 0, (hipStream_t)stream);
 }
 
 // Average wall time of `reps` back-to-back launches of each per-sample kernel (HIP events on

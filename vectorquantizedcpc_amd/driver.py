@@ -1,0 +1,100 @@
+"""Batched, length-bucketed drivers for the reference's per-utterance loops.
+
+``encode.py:42-46`` and ``convert.py:52-77`` process ONE utterance per call.  On a GPU the
+throughput comes from batching, so these drivers bucket utterances by length, zero-pad inside a
+bucket and call the batched HIP path -- while returning, for every utterance, exactly what a
+batch-1 call on that utterance alone returns:
+
+* zero right-padding is exact for the valid frames: ``nn.Conv1d(k=4, s=2, p=1)`` zero-pads there
+  anyway (``model.py:43``), everything after it is per-frame or causal (LSTM, AR loop);
+* the reference's conv back-end (and with it the fp32 summation order) depends on the CALL SHAPE
+  (``vqcpc.h``: conv_mode).  A batch-1 call uses im2col order up to 256 frames and the oneDNN order
+  above, so buckets never mix the two classes and pass the batch-1 mode explicitly;
+* every utterance keeps its own sampling-stream id (``utt_ids``), so the drawn samples do not
+  depend on the bucketing.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from .model import Encoder
+from .network_vocoder import Vocoder
+
+
+def out_frames(T: int) -> int:
+    """Code frames of a T-frame mel: Conv1d(k=4, s=2, p=1) output length (``model.py:43``)."""
+    return (T - 2) // 2 + 1
+
+
+def batch1_conv_mode(in_channels: int, T: int) -> int:
+    """Back-end ATen picks for a (1, C, T) call: 1 = im2col, 2 = oneDNN direct (``vqcpc.h``)."""
+    return 2 if in_channels * T > 20480 else 1
+
+
+def make_buckets(lengths: Sequence[int], modes: Sequence[int], max_batch: int, max_pad_frac: float):
+    """Greedy buckets over utterances sorted by (mode, length): at most ``max_batch`` members and
+    at most ``max_pad_frac`` of a bucket's frames are padding."""
+    order = sorted(range(len(lengths)), key=lambda i: (modes[i], lengths[i], i))
+    buckets, cur = [], []
+    for i in order:
+        if cur:
+            lo, hi = lengths[cur[0]], lengths[i]
+            total = sum(lengths[j] for j in cur) + lengths[i]
+            too_padded = hi * (len(cur) + 1) - total > max_pad_frac * hi * (len(cur) + 1)
+            if len(cur) >= max_batch or modes[i] != modes[cur[0]] or too_padded or lo <= 0:
+                buckets.append(cur)
+                cur = []
+        cur.append(i)
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def _pad_stack(mels: Sequence[torch.Tensor], ids: Sequence[int], device) -> torch.Tensor:
+    T = max(int(mels[i].shape[-1]) for i in ids)
+    out = torch.zeros(len(ids), mels[ids[0]].shape[0], T, device=device)
+    for k, i in enumerate(ids):
+        out[k, :, : mels[i].shape[-1]] = mels[i].to(device)
+    return out
+
+
+@torch.no_grad()
+def encode_utterances(encoder: Encoder, mels: Sequence[torch.Tensor], want_context: bool = False,
+                      max_batch: int = 64, max_pad_frac: float = 0.25):
+    """``encode.py:42-46`` over a list of (80, T_i) mels -> list of dicts with the per-utterance
+    ``z`` (T_i', 64), ``indices`` (T_i') and, if asked, ``c`` (T_i', 256)."""
+    dev = next(encoder.parameters()).device
+    C = encoder.conf.in_channels
+    lengths = [int(m.shape[-1]) for m in mels]
+    modes = [batch1_conv_mode(C, t) for t in lengths]
+    out: List[Optional[dict]] = [None] * len(mels)
+    for ids in make_buckets(lengths, modes, max_batch, max_pad_frac):
+        batch = _pad_stack(mels, ids, dev)
+        z, c, idx, _ = encoder._encode_native(batch, want_c=want_context, conv_mode=modes[ids[0]])
+        for k, i in enumerate(ids):
+            n = out_frames(lengths[i])
+            out[i] = {"z": z[k, :n], "indices": idx[k, :n], "c": c[k, :n] if want_context else None}
+    return out
+
+
+@torch.no_grad()
+def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.Tensor], speakers: Sequence[int],
+                       seed: int, utt_ids: Optional[Sequence[int]] = None, max_batch: int = 64,
+                       max_pad_frac: float = 0.25) -> List[torch.Tensor]:
+    """``convert.py:72-77`` over a list of utterances -> list of 1-D waveforms (160 * 2 * T_i' samples)."""
+    dev = next(encoder.parameters()).device
+    C = encoder.conf.in_channels
+    up = vocoder.conf.rnnms.upsampling_t
+    lengths = [int(m.shape[-1]) for m in mels]
+    modes = [batch1_conv_mode(C, t) for t in lengths]
+    utt_ids = list(range(len(mels))) if utt_ids is None else list(utt_ids)
+    out: List[Optional[torch.Tensor]] = [None] * len(mels)
+    for ids in make_buckets(lengths, modes, max_batch, max_pad_frac):
+        batch = _pad_stack(mels, ids, dev)
+        idx = encoder._encode_native(batch, want_c=False, conv_mode=modes[ids[0]])[2]
+        n_codes = [out_frames(lengths[i]) for i in ids]
+        spk = torch.tensor([int(speakers[i]) for i in ids], device=dev)
+        wav = vocoder.generate(idx, spk, n_codes=n_codes, seed=seed, utt_ids=[utt_ids[i] for i in ids])
+        for k, i in enumerate(ids):
+            out[i] = wav[k, : 2 * up * n_codes[k]]
+    return out

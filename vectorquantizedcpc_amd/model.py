@@ -124,16 +124,17 @@ class Encoder(nn.Module):
         _lib.require_cuda(mel, "mel")
         if mel.dim() != 3 or mel.size(1) != self.conf.in_channels:
             raise RuntimeError(f"expected mel of shape (B, {self.conf.in_channels}, T), got {tuple(mel.shape)}")
-        if mel.size(2) % 2 != 0:
-            mel = mel[:, :, : mel.size(2) - 1]       # Conv1d(k4,s2,p1) ignores a trailing odd frame (model.py:43)
+        if mel.size(2) < 2:
+            raise RuntimeError("Conv1d(k=4, s=2, p=1) needs at least 2 mel frames")
         mel = mel.detach().to(torch.float32).contiguous()
         B, _, T = mel.shape
+        To = (T - 2) // 2 + 1                        # nn.Conv1d(k4, s2, p1) output length (model.py:43)
         h = self._native()
         dev = mel.device
-        z = torch.empty(B, T // 2, self.conf.z_dim, device=dev)
+        z = torch.empty(B, To, self.conf.z_dim, device=dev)
         z_pre = torch.empty_like(z)
-        idx = torch.empty(B, T // 2, dtype=torch.int64, device=dev)
-        c = torch.empty(B, T // 2, self.conf.c_dim, device=dev) if want_c else None
+        idx = torch.empty(B, To, dtype=torch.int64, device=dev)
+        c = torch.empty(B, To, self.conf.c_dim, device=dev) if want_c else None
         with torch.cuda.device(dev):
             _lib.check(_lib.load().vqcpc_encoder_encode(
                 h, mel.data_ptr(), B, T, conv_mode, z.data_ptr(), c.data_ptr() if want_c else None,
@@ -161,7 +162,7 @@ class Encoder(nn.Module):
         mel = mel.detach().to(torch.float32).contiguous()
         B, _, T = mel.shape
         F = self.conf.z_dim if stage == 10 else self.conf.channels
-        out = torch.empty(B, T // 2, F, device=mel.device)
+        out = torch.empty(B, (T - 2) // 2 + 1, F, device=mel.device)
         with torch.cuda.device(mel.device):
             _lib.check(_lib.load().vqcpc_encoder_stage(self._native(), mel.data_ptr(), B, T, conv_mode, stage,
                                                        out.data_ptr(), _lib.current_stream()))

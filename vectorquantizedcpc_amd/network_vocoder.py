@@ -171,13 +171,14 @@ class Vocoder(nn.Module):
                 speaker.detach().to(device=z.device, dtype=torch.int64).contiguous())
 
     @torch.no_grad()
-    def generate(self, z: Tensor, speaker: Tensor, *, n_codes=None, seed=None, utt_base=None,
+    def generate(self, z: Tensor, speaker: Tensor, *, n_codes=None, seed=None, utt_base=None, utt_ids=None,
                  return_mulaw: bool = False, max_steps: int = 0):
         """``network_vocoder.py:69-78``: waveform (B, 2*upsampling_t*T') from code indices and speaker ids.
 
         Keyword extras (not in the reference): ``n_codes`` per-utterance valid code counts of a
-        padded batch; ``seed`` / ``utt_base`` of the sampling protocol (default: torch's seed and
-        the number of utterances this module has generated so far); ``return_mulaw`` also returns
+        padded batch; ``seed`` / ``utt_base`` / ``utt_ids`` of the sampling protocol (default: torch's
+        seed and the number of utterances this module has generated so far; ``utt_ids`` gives every
+        row its own stream id, so results do not depend on batching); ``return_mulaw`` also returns
         the int64 mu-law classes.
         """
         z, speaker = self._prep(z, speaker)
@@ -189,13 +190,17 @@ class Vocoder(nn.Module):
         seed = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
         if utt_base is None:
             utt_base = self._utterances_done
-            self._utterances_done += B
+            if utt_ids is None:
+                self._utterances_done += B
+        ids = None
+        if utt_ids is not None:
+            ids = (C.c_uint32 * B)(*[int(v) & 0xFFFFFFFF for v in utt_ids])
         nc = None
         if n_codes is not None:
             nc = (C.c_int * B)(*[int(v) for v in n_codes])
         with torch.cuda.device(z.device):
             _lib.check(_lib.load().vqcpc_vocoder_generate(
-                h, z.data_ptr(), speaker.data_ptr(), B, Tc, nc, seed, int(utt_base) & 0xFFFFFFFF, wav.data_ptr(),
+                h, z.data_ptr(), speaker.data_ptr(), B, Tc, nc, seed, int(utt_base) & 0xFFFFFFFF, ids, wav.data_ptr(),
                 mulaw.data_ptr() if return_mulaw else None, int(max_steps), _lib.current_stream()))
         return (wav, mulaw) if return_mulaw else wav
 
