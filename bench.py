@@ -172,6 +172,17 @@ def main():
     gru_flop = 2.0 * 2408448 * Bp
     achieved = gru_flop / (gru_us * 1e-6) / 1e12
     step_tflops = FLOP_PER_SAMPLE * Bp / (step_us * 1e-6) / 1e12
+    # HBM-side bytes per launch of that kernel: collected offline with rocprofv3 --pmc (separate
+    # passes, gfx950 FETCH_SIZE correction applied) -- profiles/r01_pmc_traffic.json, same batch only
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pmc.get("utterances") == Bp:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
+    gru_bytes = 4.0 * (2408448 + Bp * (2 * 896 + 2 * 3 * 896))
 
     result = {
         "metric": "audio samples/sec (WaveRNN-style decode, convert.py path: encode + generate)",
@@ -186,7 +197,9 @@ def main():
         "realtime_factor_16k_per_gpu": value / 16000.0 / world,
         "roofline": {"bound": "mfma", "kernel": "ar_gru_kernel<14> (GRU step: W_hh h for all utterances + cell update)",
                      "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; mostly Infinity-Cache hits)",
+                     "algorithmic_bytes_per_launch": gru_bytes,
                      "flop_per_launch": gru_flop, "avg_launch_us": gru_us,
                      "how": "HIP events on the launch stream around 2000 back-to-back launches (includes the "
                             "~1.5 us dependent-launch boundary)",
