@@ -48,19 +48,20 @@ def build_models(dev):
 
 
 def timed(fn, steps, warmup, dev, world):
+    ddp = dist.is_available() and dist.is_initialized()
     for _ in range(warmup):
         fn()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if ddp:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -132,14 +133,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torch.distributed.run
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+    if launched:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N"
 
     enc, voc = build_models(dev)
     if os.environ.get("VQCPC_BENCH_NO_GRAPH"):           # counter collection (rocprofv3 --pmc) needs plain launches
@@ -155,9 +157,10 @@ def main():
     def step():
         idx = enc.encode_indices(mel)                         # convert.py:76 (context discarded)
         wav = voc.generate(idx, spk, seed=synth.SEED, utt_base=ids[0])
-        if world > 1:
+        if launched:
             out = [torch.empty_like(wav) for _ in range(world)] if rank == 0 else None
             dist.gather(wav, out, dst=0)                      # the one exchange step (RCCL over xGMI)
+            state["gathered"] = out
         state["wav"] = wav
 
     log(f"models built; timing {args.steps} step(s) of {Bp} utterances x {L} samples on {world} GPU(s)")
@@ -244,7 +247,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(Bp)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

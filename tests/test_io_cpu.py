@@ -1,0 +1,51 @@
+"""File formats of the reference's CLIs (encode.py / convert.py), CPU side."""
+import json
+
+import numpy as np
+import torch
+
+from vectorquantizedcpc_amd import io, synth
+
+
+def test_frames_text_is_the_reference_format(tmp_path):
+    z = synth.mel("io", 1, 7, n_mels=64)[0].T.contiguous()          # (7, 64) float32
+    io.save_frames_text(tmp_path / "utt", z)
+    ref = tmp_path / "ref.txt"
+    with open(ref, "w") as f:
+        np.savetxt(f, z.numpy(), fmt="%.16f")                       # encode.py:50-52 verbatim call
+    assert (tmp_path / "utt.txt").read_bytes() == ref.read_bytes()
+    assert np.array_equal(io.load_frames_text(tmp_path / "utt"), z.numpy())   # %.16f round-trips float32
+
+
+def test_mel_wav_and_metadata(tmp_path):
+    mel = synth.mel("io2", 1, 33)[0]
+    np.save(tmp_path / "a.mel.npy", mel.numpy())
+    assert torch.equal(io.load_mel(tmp_path / "a"), mel) and torch.equal(io.load_mel(tmp_path / "a.mel.npy"), mel)
+    wav = torch.linspace(-1, 1, 1600)
+    io.save_wav(tmp_path / "o", wav)
+    from scipy.io import wavfile
+    sr, back = wavfile.read(tmp_path / "o.wav")
+    assert sr == 16000 and back.dtype == np.float32 and np.array_equal(back, wav.numpy())
+    ds = tmp_path / "datasets" / "eng"
+    ds.mkdir(parents=True)
+    (ds / "test.json").write_text(json.dumps([["x", 0, 1, "eng/test/S1_a"], ["y", 0, 1, "eng/test/S2_b"]]))
+    (ds / "speakers.json").write_text(json.dumps(["V002", "V001"]))
+    assert [p.name for p in io.read_test_metadata(ds)] == ["S1_a", "S2_b"]
+    assert io.read_test_metadata(ds)[0].parent == tmp_path / "datasets" / "eng" / "test"
+    (tmp_path / "list.json").write_text(json.dumps([["eng/test/S1_a", "V002", "out1"]]))
+    items, speakers = io.read_synthesis_list(tmp_path / "list.json", ds / "speakers.json")
+    assert speakers == ["V001", "V002"] and items == [("eng/test/S1_a", 1, "out1")]
+
+
+def test_checkpoint_layouts(tmp_path):
+    sd = synth.encoder_state_dict()
+    torch.save({"encoder": sd, "epoch": 3}, tmp_path / "cpc.pt")                 # train_cpc.py:23-29
+    got = io.load_encoder_checkpoint(tmp_path / "cpc.pt")
+    assert list(got.keys()) == list(sd.keys()) and torch.equal(got["conv.weight"], sd["conv.weight"])
+    vsd = synth.vocoder_state_dict()
+    torch.save({"state_dict": {**{"model." + k: v for k, v in vsd.items()}, "encoder.conv.weight": sd["conv.weight"]}},
+               tmp_path / "last.ckpt")                                            # Lightning layout (vocoder.py:47-48)
+    got = io.load_vocoder_checkpoint(tmp_path / "last.ckpt")
+    assert set(got.keys()) == set(vsd.keys())
+    torch.save({"vocoder": vsd}, tmp_path / "voc.pt")                             # convert.py:45
+    assert set(io.load_vocoder_checkpoint(tmp_path / "voc.pt").keys()) == set(vsd.keys())

@@ -1,0 +1,78 @@
+"""On-disk formats of the reference's inference CLIs.
+
+* input mels: ``<path>.mel.npy`` float (80, T) (``encode.py:44``)
+* metadata: ``test.json`` = list of ``[.., .., .., path]`` (``encode.py:18-20, :42``);
+  ``speakers.json`` = list of speaker names, sorted (``convert.py:19-20``);
+  synthesis list = ``[[utterance_path, speaker_id, out_filename], ...]`` (``convert.py:22-24, :52``)
+* encoder checkpoint: ``torch.load(path)["encoder"]`` (``train_cpc.py:23-29``, ``encode.py:29-30``)
+* code vectors: one text row per frame, ``np.savetxt(fmt="%.16f")`` (``encode.py:50-52``), same for the
+  auxiliary context / pre-VQ dumps (``encode.py:54-67``)
+* audio out: 16 kHz float32 WAV (``convert.py:83`` wrote ``output.astype(np.float32)``)
+"""
+import json
+from pathlib import Path
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def load_mel(path) -> torch.Tensor:
+    """``np.load(path.with_suffix('.mel.npy'))`` -> float32 (80, T) tensor (``encode.py:44``)."""
+    p = Path(path)
+    if p.suffix != ".npy":
+        p = p.with_suffix(".mel.npy")
+    a = np.load(p, allow_pickle=False)
+    if a.ndim != 2:
+        raise ValueError(f"{p}: expected a (n_mels, T) array, got shape {a.shape}")
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def save_frames_text(path, frames) -> None:
+    """One row per frame, ``%.16f`` (``encode.py:50-52``)."""
+    a = frames.detach().cpu().numpy() if hasattr(frames, "detach") else np.asarray(frames)
+    with open(Path(path).with_suffix(".txt"), "w") as f:
+        np.savetxt(f, a, fmt="%.16f")
+
+
+def load_frames_text(path) -> np.ndarray:
+    return np.loadtxt(Path(path).with_suffix(".txt"), dtype=np.float64, ndmin=2).astype(np.float32)
+
+
+def save_wav(path, wav, sr: int = 16000) -> None:
+    """float32 WAV (``convert.py:83``)."""
+    from scipy.io import wavfile
+    a = wav.detach().cpu().numpy() if hasattr(wav, "detach") else np.asarray(wav)
+    wavfile.write(str(Path(path).with_suffix(".wav")), sr, a.astype(np.float32))
+
+
+def load_encoder_checkpoint(path) -> Dict[str, torch.Tensor]:
+    """``checkpoint["encoder"]`` with a loader that executes nothing from the file."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    return ck["encoder"] if "encoder" in ck else ck
+
+
+def load_vocoder_checkpoint(path) -> Dict[str, torch.Tensor]:
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    if "vocoder" in ck:                       # convert.py:45
+        return ck["vocoder"]
+    if "state_dict" in ck:                    # Lightning checkpoint rooted at VocoderModel.model (vocoder.py:47)
+        return {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+    return ck
+
+
+def read_test_metadata(dataset_root) -> List[Path]:
+    """``datasets/<name>/test.json`` -> utterance paths relative to ``datasets/`` (``encode.py:18-20, :42-43``)."""
+    root = Path(dataset_root)
+    with open(root / "test.json") as f:
+        meta = json.load(f)
+    return [root.parent / row[3] for row in meta]
+
+
+def read_synthesis_list(list_path, speakers_path) -> Tuple[List[Tuple[str, int, str]], List[str]]:
+    """(utterance, speaker index, output name) triples and the sorted speaker list (``convert.py:19-24, :73``)."""
+    with open(speakers_path) as f:
+        speakers = sorted(json.load(f))
+    with open(list_path) as f:
+        items = json.load(f)
+    return [(str(p), speakers.index(s), str(o)) for p, s, o in items], speakers
