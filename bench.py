@@ -114,6 +114,33 @@ def cpu_baseline(n_utt, budget_s=12.0):
             "encoder_frames_per_s": 64 * 64 / de}
 
 
+def synthetic_manifest(n, seed=synth.SEED):
+    """BASELINE configs[4] stand-in: the reference ships no test-set manifest (datasets are
+    git-ignored), so lengths are drawn log-normally between 1 and 10 s (seeded), speakers round-robin."""
+    import numpy as np
+    u = synth.uniform01("bench/manifest", 2 * n, seed).reshape(n, 2)
+    g = np.sqrt(-2.0 * np.log(np.maximum(u[:, 0], 1e-12))) * np.cos(2 * np.pi * u[:, 1])      # host-side only
+    secs = np.clip(np.exp(np.log(3.0) + 0.5 * g), 1.0, 10.0)
+    frames = (secs * 100).astype(int)                           # 10 ms hop
+    return [int(f) for f in frames], [i % 102 for i in range(n)]
+
+
+def run_manifest(enc, voc, dev, n_utt, max_batch):
+    from vectorquantizedcpc_amd import driver
+    frames, spk = synthetic_manifest(n_utt)
+    mels = [synth.mel(f"bench/man{i % 8}", 1, max(frames))[0][:, :f].contiguous().to(dev) for i, f in enumerate(frames)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    wavs = driver.convert_utterances(enc, voc, mels, spk, seed=synth.SEED, max_batch=64, max_pad_frac=0.15, slots=max_batch)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    samples = sum(int(w.numel()) for w in wavs)
+    return {"workload": f"synthetic manifest (configs[4] stand-in): {n_utt} utterances, log-normal 1-10 s, "
+                        f"encoder in length buckets, decode by continuous batching over {max_batch} slots",
+            "utterances": n_utt, "audio_seconds": samples / 16000.0, "wall_s": dt,
+            "samples_per_s": samples / dt, "realtime_factor_16k": samples / 16000.0 / dt}
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -126,6 +153,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--utterances-per-gpu", type=int, default=32)
     ap.add_argument("--frames", type=int, default=200, help="mel frames per utterance (200 = 2 s = 32 000 samples)")
+    ap.add_argument("--manifest", type=int, default=0, help="also run a synthetic ragged manifest of this many utterances")
+    ap.add_argument("--manifest-batch", type=int, default=128, help="decode slots of the manifest workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -243,6 +272,9 @@ def main():
         d1 = time.perf_counter() - t0
         result["single_utterance"] = {"workload": "BASELINE configs[2]: 1 utterance x 32 000 samples",
                                       "samples_per_s": 32000 / d1, "realtime_factor_16k": 2.0 / d1}
+    if rank == 0 and world == 1 and args.manifest > 0:
+        log(f"manifest workload: {args.manifest} utterances")
+        result["manifest"] = run_manifest(enc, voc, dev, args.manifest, args.manifest_batch)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Bp)
     if rank == 0:

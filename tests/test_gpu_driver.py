@@ -47,6 +47,8 @@ def test_convert_utterances_equals_batch1_calls():
     mels = [synth.mel(f"cv/{i}", 1, t)[0] for i, t in enumerate(Ts)]
     spk = [3, 50, 7, 101]
     got = driver.convert_utterances(enc, voc, mels, spk, seed=13, max_batch=3, max_pad_frac=0.5)
+    got_cb = driver.convert_utterances(enc, voc, mels, spk, seed=13, max_batch=3, slots=2)      # continuous batching
+    assert all(torch.equal(a, b) for a, b in zip(got, got_cb))
     for i, m in enumerate(mels):
         idx = enc.encode_indices(m[None].cuda())
         wav = voc.generate(idx, torch.tensor([spk[i]], device="cuda"), seed=13, utt_ids=[i])

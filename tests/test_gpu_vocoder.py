@@ -133,3 +133,22 @@ def test_full_length_utterance_properties():
     assert mu.min() >= 0 and mu.max() <= 255 and mu.unique().numel() > 32
     ms, n = voc.last_timing()
     assert n == 32000 and ms > 0
+
+
+def test_continuous_batching_equals_static_batches():
+    """Decode slots reused by successive utterances (vqcpc_vocoder_set_option "slots") produce,
+    for every utterance, the bits of a plain batched call."""
+    voc, _ = vocoder()
+    z = synth.randint("cb/z", (7, 4), 512)
+    spk = synth.randint("cb/spk", (7,), 102)
+    n_codes = [4, 1, 3, 2, 4, 1, 2]
+    ids = [11, 12, 13, 14, 15, 16, 17]
+    ref_w, ref_m = voc.generate(z.cuda(), spk.cuda(), n_codes=n_codes, seed=21, utt_ids=ids, return_mulaw=True)
+    for slots in (2, 3):
+        voc.set_option("slots", slots)
+        try:
+            w, m = voc.generate(z.cuda(), spk.cuda(), n_codes=n_codes, seed=21, utt_ids=ids, return_mulaw=True)
+        finally:
+            voc.set_option("slots", 0)
+        assert torch.equal(m, ref_m) and torch.equal(w, ref_w), slots
+    assert int((ref_m[1, 320:] != 0).sum()) == 0 and int((ref_m[0] != 0).sum()) > 1000

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -232,14 +233,20 @@ int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream
 // 16 candidates per utterance are merged by the next step's GRU kernel.
 // Per-call quantities live in a device-side ArCall so one captured graph serves every call.
 // ------------------------------------------------------------------------------------------
+// Continuous batching: a decode SLOT (one MFMA column) runs utterances back to back.  Utterances
+// start at replay boundaries, so per (replay, slot) there is at most one: row = its index in this
+// call's inputs/outputs (-1 = idle), t0 = global step of its sample 0, len = its samples,
+// utt = its sampling-stream id.
+struct ArSlot { int row, t0, len; unsigned utt; };
+
 struct ArCall {
     const float *Gcond;        // [Bpad][F][3Hr] = W_ih[:, de:] cond + b_ih
     const int64_t *inputs;     // teacher forcing (B, Ts) or null
     float *wav;                // (B, Lout) or null
     int64_t *mulaw;            // (B, Lout) or null
     float *logits;             // (B, Ts, n_cls) or null
-    const int *len;            // [Bpad] samples per utterance
-    const unsigned *utt;       // [Bpad] sampling-stream id of each utterance
+    const ArSlot *slots;       // [replays][Sp] what every decode slot is doing during each graph replay
+    int S, Sp;                 // steps per replay (t_base is a multiple of it), slots (multiple of 16)
     int F, Ts, Lout, max_t, nbt;
     unsigned long long seed;
     int t_base;                // advanced on device after every graph replay
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
     // pass's fragment loads with another's MFMAs when many utterances are in flight
     {
         const int bt0 = blockIdx.y * NB;
-        bool active = false;
+        bool active = false, first = false;
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
         size_t hi = 0;
         if (mfma_wave) {
@@ -350,40 +357,44 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             }
         } else {
             const int bt = bt0 + g;
-            const int bg = (bt < nbt ? bt : nbt - 1) * 16 + b;
+            const int sg = (bt < nbt ? bt : nbt - 1) * 16 + b;           // decode slot
             Cand cd;
-            load_candidates(m, bg, cd);
+            load_candidates(m, sg, cd);
             const ArCall c = *cp;
             const int t = c.t_base + t_local;
-            active = bt < nbt && t < c.max_t && t < c.len[bg];
+            const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
+            const int lt = t - sl.t0;                                    // sample index inside the utterance
+            active = bt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
+            first = lt == 0;
             if (active) {
                 int x;
-                if (c.inputs) x = (int)c.inputs[(size_t)bg * c.Ts + t];
-                else if (t == 0) x = m.n_cls / 2;
+                if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
+                else if (first) x = m.n_cls / 2;
                 else {
                     x = merge_candidates(cd);
-                    if (rg == 0 && u == 0) {                    // emit sample t-1 (network_vocoder.py:78 output)
-                        if (c.wav) c.wav[(size_t)bg * c.Lout + t - 1] = m.mulaw_tab[x];
-                        if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + t - 1] = x;
+                    if (rg == 0 && u == 0) {                    // emit sample lt-1 (network_vocoder.py:78 output)
+                        if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
+                        if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
                     }
                 }
                 x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
                 const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
-                const float *gc = c.Gcond + ((size_t)bg * c.F + t / m.upsample) * 3 * Hr + unit;
+                const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
                 const float *bh = m.b_hh + unit;
-                hi = hl_index(Hr, bg, unit);
+                hi = hl_index(Hr, sg, unit);
                 ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
                 gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
                 bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
-                hold = hin[hi];
+                hold = first ? 0.f : hin[hi];                   // a new utterance starts from h = 0
             }
         }
         __syncthreads();
         // cell update (PyTorch GRUCell equations, gate order r, z, n), K quarters summed in fixed order
         if (active) {
-            const float gr = ((red[g][0][u][b] + red[g][1][u][b]) + red[g][2][u][b]) + red[g][3][u][b];
-            const float gz = ((red[g][0][4 + u][b] + red[g][1][4 + u][b]) + red[g][2][4 + u][b]) + red[g][3][4 + u][b];
-            const float gn = ((red[g][0][8 + u][b] + red[g][1][8 + u][b]) + red[g][2][8 + u][b]) + red[g][3][8 + u][b];
+            // the slot's previous occupant left its state in the MFMA operand: W_hh . 0 = 0 on a first step
+            const float gr = first ? 0.f : ((red[g][0][u][b] + red[g][1][u][b]) + red[g][2][u][b]) + red[g][3][u][b];
+            const float gz = first ? 0.f : ((red[g][0][4 + u][b] + red[g][1][4 + u][b]) + red[g][2][4 + u][b]) + red[g][3][4 + u][b];
+            const float gn = first ? 0.f : ((red[g][0][8 + u][b] + red[g][1][8 + u][b]) + red[g][2][8 + u][b]) + red[g][3][8 + u][b];
             const float r = sigmoidf_((ge0 + gc0) + (gr + bh0));
             const float z = sigmoidf_((ge1 + gc1) + (gz + bh1));
             const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
@@ -439,16 +450,18 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     float4 wf[4], hv[4];
     load_wfrag<4>(m.Wf_fc2, rg, 4, wave, lane, wf);
     load_hfrag<4>(m.a1, m.Hf, bt, wave, lane, hv);
-    const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;
+    const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;      // bg = decode slot
     const float bias = m.b_fc2[cls];
     __builtin_amdgcn_sched_barrier(0);
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
-    // noise of (class, utterance) while the loads fly
-    const unsigned w = philox_word((unsigned)t, c.utt[bg], (unsigned)(cls >> 2), (unsigned)c.seed,
+    const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + bg];
+    const int lt = t - sl.t0;
+    // noise of (class, utterance, sample) while the loads fly
+    const unsigned w = philox_word((unsigned)lt, sl.utt, (unsigned)(cls >> 2), (unsigned)c.seed,
                                    (unsigned)(c.seed >> 32), cls & 3);
     const float g = -logf(-logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f)));
-    const bool live = t < c.max_t && t < c.len[bg];
+    const bool live = t < c.max_t && sl.row >= 0 && lt < sl.len;
     __builtin_amdgcn_sched_barrier(0);
     const f32x4 acc = mfma_frag<4>(wf, hv);
 #pragma unroll
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     __syncthreads();
     float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
     v += bias;
-    if (c.logits && live) c.logits[((size_t)bg * c.Ts + t) * m.n_cls + cls] = v;
+    if (c.logits && live) c.logits[((size_t)sl.row * c.Ts + lt) * m.n_cls + cls] = v;
     sc[rr][bb] = v + g;
     __syncthreads();
     if (tid < 16 && live) {
@@ -472,18 +485,21 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
 
 __global__ void ar_advance_kernel(ArCall *c, int n) { c->t_base += n; }
 
-// After the loop: the last sample of every utterance is still only a set of candidates.
-__global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp, int Bpad) {
-    const int bg = blockIdx.x * blockDim.x + threadIdx.x;
+// End of every replay: an utterance whose last sample fell inside this replay still has that sample
+// only as candidates (the next GRU step would have merged them): emit it before the slot is reused.
+__global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
+    const int sg = blockIdx.x * blockDim.x + threadIdx.x;
     const ArCall c = *cp;
-    if (bg >= Bpad || c.inputs) return;
-    const int n = c.len[bg];
-    if (n <= 0) return;
+    if (sg >= c.Sp || c.inputs) return;
+    const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
+    if (sl.row < 0) return;
+    const int end = sl.t0 + sl.len;
+    if (end <= c.t_base || end > c.t_base + c.S) return;
     Cand cd;
-    load_candidates(m, bg, cd);
+    load_candidates(m, sg, cd);
     const int x = merge_candidates(cd);
-    if (c.wav) c.wav[(size_t)bg * c.Lout + n - 1] = m.mulaw_tab[x];
-    if (c.mulaw) c.mulaw[(size_t)bg * c.Lout + n - 1] = x;
+    if (c.wav) c.wav[(size_t)sl.row * c.Lout + sl.len - 1] = m.mulaw_tab[x];
+    if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + sl.len - 1] = x;
 }
 
 // Vocoder glue (network_vocoder.py:73-77): series[b, t2, :dz] = code_emb[idx[b, t2/2]], [dz:] = spk_emb[spk[b]]
@@ -528,6 +544,8 @@ struct vqcpc_vocoder {
     ArCall *call = nullptr;              // device
     DevBuf series, gi, out0, cond, gcond, hseq, har, a1, cand_s, cand_k, len;
     int use_graph = 1, steps_per_graph = 160;
+    int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
+    DevBuf slot_tab;
     std::map<int, hipGraphExec_t> graphs; // key: nbt
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -552,7 +570,8 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
                      v->Wf_fc1, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (v->call) (void)hipFree(v->call);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->har, &v->a1, &v->cand_s, &v->cand_k, &v->len};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->har, &v->a1, &v->cand_s, &v->cand_k, &v->len,
+                      &v->slot_tab};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -649,6 +668,11 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         v->steps_per_graph = value;
         return VQCPC_OK;
     }
+    if (!strcmp(name, "slots")) {
+        VQ_REQUIRE(value >= 0 && value <= 65536, "slots out of range");
+        v->n_slots = value;
+        return VQCPC_OK;
+    }
     vq_set_error("unknown option %s", name);
     return VQCPC_ERR_INVALID;
 }
@@ -705,6 +729,7 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, h
         }
         hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i);
     }
+    hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)v->call);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, v->call, n);
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
@@ -716,11 +741,12 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
                   const uint32_t *utt_ids_host, float *wav,
                   int64_t *mulaw, float *logits, int max_steps, hipStream_t s) {
     const auto &d = v->d;
-    const int Hr = d.Hr, dl = 2 * d.Hp, T2 = 2 * Tc, nbt = (B + 15) / 16, Bp = nbt * 16;
+    const int Hr = d.Hr, dl = 2 * d.Hp, T2 = 2 * Tc, Bp = (B + 15) / 16 * 16;
     const int Lout = d.upsample_t * T2;
+    const int S = v->steps_per_graph;
     // per-utterance lengths: frames for the prenet, samples for the AR loop
-    std::vector<int> lens(3 * Bp, 0);     // [frames | samples | sampling-stream ids]
-    int max_t = 0;
+    std::vector<int> lens(2 * Bp, 0);     // [frames | samples]
+    std::vector<unsigned> utt(B);
     bool ragged = false;
     for (int b = 0; b < B; ++b) {
         int nc = n_codes_host ? n_codes_host[b] : Tc;
@@ -731,35 +757,62 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         if (inputs) ns = ns < Ts ? ns : Ts;
         if (max_steps > 0 && ns > max_steps) ns = max_steps;
         lens[Bp + b] = ns;
-        lens[2 * Bp + b] = (int)(utt_ids_host ? utt_ids_host[b] : utt_base + (unsigned)b);
-        max_t = ns > max_t ? ns : max_t;
+        utt[b] = utt_ids_host ? utt_ids_host[b] : utt_base + (unsigned)b;
     }
+    // Decode-slot schedule (continuous batching): longest utterance first onto the slot that frees
+    // up first; an utterance starts at a replay boundary.  n_slots >= B: everything starts at 0.
+    int n_slots = (v->n_slots > 0 && v->n_slots < B && !inputs) ? v->n_slots : B;
+    const int nbt = (n_slots + 15) / 16, Sp = nbt * 16;
+    std::vector<int> order(B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[Bp + a] > lens[Bp + b]; });
+    std::vector<long> slot_end(n_slots, 0);
+    struct Seg { int slot, row, t0, len; };
+    std::vector<Seg> segs;
+    long total = 0;
+    for (int row : order) {
+        const int len = lens[Bp + row];
+        if (len <= 0) continue;
+        int best = 0;
+        for (int q = 1; q < n_slots; ++q) if (slot_end[q] < slot_end[best]) best = q;
+        segs.push_back({best, row, (int)slot_end[best], len});
+        slot_end[best] = (slot_end[best] + len + S - 1) / S * S;
+        total = slot_end[best] > total ? slot_end[best] : total;
+    }
+    VQ_REQUIRE(total < (1L << 30), "vocoder: schedule too long");
+    const int max_t = (int)total, n_rep = max_t / S;
+    std::vector<ArSlot> table((size_t)(n_rep > 0 ? n_rep : 1) * Sp, ArSlot{-1, 0, 0, 0u});
+    for (const Seg &g : segs)
+        for (int r = g.t0 / S; r < (g.t0 + g.len + S - 1) / S; ++r)
+            table[(size_t)r * Sp + g.slot] = ArSlot{g.row, g.t0, g.len, utt[g.row]};
     TRY(v->len.reserve(lens.size() * sizeof(int)));
+    TRY(v->slot_tab.reserve(table.size() * sizeof(ArSlot)));
     HIP_TRY(hipMemcpyAsync(v->len.p, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));     // lens is a stack-lifetime host buffer
+    HIP_TRY(hipMemcpyAsync(v->slot_tab.p, table.data(), table.size() * sizeof(ArSlot), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));     // host vectors above die with this frame
     const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
-    const int *samples_dev = v->len.as<int>() + Bp;
 
     const size_t rows = (size_t)B * T2;
     TRY(v->cond.reserve(rows * dl * sizeof(float)));
     TRY(run_condition(v, idx, spk, B, Tc, frames_dev, v->cond.as<float>(), s));
-    TRY(v->gcond.reserve((size_t)Bp * T2 * 3 * Hr * sizeof(float)));
+    TRY(v->gcond.reserve(rows * 3 * Hr * sizeof(float)));
     TRY(vq_gemm_chain(v->cond.as<float>(), dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)rows, 3 * Hr, dl, dl, s));
 
     const size_t hsz = (size_t)nbt * Hr * 16 * sizeof(float);
     TRY(v->har.reserve(2 * hsz));
     TRY(v->a1.reserve((size_t)nbt * d.Hf * 16 * sizeof(float)));
-    TRY(v->cand_s.reserve((size_t)Bp * 16 * sizeof(float)));
-    TRY(v->cand_k.reserve((size_t)Bp * 16 * sizeof(int)));
+    TRY(v->cand_s.reserve((size_t)Sp * 16 * sizeof(float)));
+    TRY(v->cand_k.reserve((size_t)Sp * 16 * sizeof(int)));
     HIP_TRY(hipMemsetAsync(v->har.p, 0, 2 * hsz, s));
-    HIP_TRY(hipMemsetAsync(v->cand_s.p, 0, (size_t)Bp * 16 * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(v->cand_k.p, 0, (size_t)Bp * 16 * sizeof(int), s));
-    if (wav && (ragged || max_steps > 0)) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
-    if (mulaw && (ragged || max_steps > 0)) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
+    HIP_TRY(hipMemsetAsync(v->cand_s.p, 0, (size_t)Sp * 16 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(v->cand_k.p, 0, (size_t)Sp * 16 * sizeof(int), s));
+    if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
+    if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
     ArCall c{};
     c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
-    c.len = samples_dev; c.utt = (const unsigned *)(v->len.as<int>() + 2 * Bp); c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.t_base = 0;
+    c.slots = v->slot_tab.as<ArSlot>(); c.S = S; c.Sp = Sp;
+    c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.t_base = 0;
     HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));     // c is a stack-lifetime host buffer
 
@@ -769,7 +822,6 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     m.hbuf = v->har.as<float>(); m.a1 = v->a1.as<float>(); m.cand_s = v->cand_s.as<float>(); m.cand_k = v->cand_k.as<int>();
     m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
 
-    const int S = v->steps_per_graph;
     HIP_TRY(hipEventRecord(v->ev0, s));
     if (v->use_graph) {
         // The graph bakes ArModel (buffer pointers): drop cached graphs if a workspace moved.
@@ -796,7 +848,6 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     } else {
         for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, nbt, S, s));
     }
-    hipLaunchKernelGGL(ar_finalize_kernel, dim3((Bp + 63) / 64), dim3(64), 0, s, m, (const ArCall *)v->call, Bp);
     HIP_TRY(hipEventRecord(v->ev1, s));
     v->last_steps = max_t;
     v->last_call = c; v->last_model = m; v->have_last = true;

@@ -80,21 +80,44 @@ def encode_utterances(encoder: Encoder, mels: Sequence[torch.Tensor], want_conte
 @torch.no_grad()
 def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.Tensor], speakers: Sequence[int],
                        seed: int, utt_ids: Optional[Sequence[int]] = None, max_batch: int = 64,
-                       max_pad_frac: float = 0.25) -> List[torch.Tensor]:
-    """``convert.py:72-77`` over a list of utterances -> list of 1-D waveforms (160 * 2 * T_i' samples)."""
+                       max_pad_frac: float = 0.25, slots: int = 0) -> List[torch.Tensor]:
+    """``convert.py:72-77`` over a list of utterances -> list of 1-D waveforms (160 * 2 * T_i' samples).
+
+    ``slots`` > 0: continuous batching -- ONE decode call over all utterances with that many decode
+    slots, each slot running utterances back to back (longest first), instead of one call per
+    length bucket.  The samples are the same either way (per-utterance sampling streams).
+    """
     dev = next(encoder.parameters()).device
     C = encoder.conf.in_channels
     up = vocoder.conf.rnnms.upsampling_t
     lengths = [int(m.shape[-1]) for m in mels]
     modes = [batch1_conv_mode(C, t) for t in lengths]
     utt_ids = list(range(len(mels))) if utt_ids is None else list(utt_ids)
+    n_codes_all = [out_frames(t) for t in lengths]
     out: List[Optional[torch.Tensor]] = [None] * len(mels)
+    codes: List[Optional[torch.Tensor]] = [None] * len(mels)
     for ids in make_buckets(lengths, modes, max_batch, max_pad_frac):
         batch = _pad_stack(mels, ids, dev)
         idx = encoder._encode_native(batch, want_c=False, conv_mode=modes[ids[0]])[2]
-        n_codes = [out_frames(lengths[i]) for i in ids]
+        if slots > 0:
+            for k, i in enumerate(ids):
+                codes[i] = idx[k, : n_codes_all[i]]
+            continue
+        n_codes = [n_codes_all[i] for i in ids]
         spk = torch.tensor([int(speakers[i]) for i in ids], device=dev)
         wav = vocoder.generate(idx, spk, n_codes=n_codes, seed=seed, utt_ids=[utt_ids[i] for i in ids])
         for k, i in enumerate(ids):
             out[i] = wav[k, : 2 * up * n_codes[k]]
+    if slots > 0:
+        idx = torch.zeros(len(mels), max(n_codes_all), dtype=torch.int64, device=dev)
+        for i, cd in enumerate(codes):
+            idx[i, : cd.numel()] = cd
+        spk = torch.tensor([int(v) for v in speakers], device=dev)
+        vocoder.set_option("slots", slots)
+        try:
+            wav = vocoder.generate(idx, spk, n_codes=n_codes_all, seed=seed, utt_ids=utt_ids)
+        finally:
+            vocoder.set_option("slots", 0)
+        for i in range(len(mels)):
+            out[i] = wav[i, : 2 * up * n_codes_all[i]]
     return out
