@@ -171,7 +171,10 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
                             int B, int Tc, float *cond, void *stream);
 
 /* Decode-loop options.  use_graph: replay the per-sample kernels from a captured hipGraph
- * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay. */
+ * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
+ * slots: continuous batching -- decode with this many slots, each running utterances back to back
+ * (0 = one slot per utterance).  big_min_tiles: utterance tiles (of 16) from which the LDS-staged
+ * large-batch GRU kernel is used (default 8, 0 = never). */
 int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
 
 /* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call

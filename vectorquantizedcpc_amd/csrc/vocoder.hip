@@ -262,17 +262,17 @@ struct ArModel {               // constant per handle (baked into the captured g
     int Hr, Hf, n_cls, upsample;
 };
 
-// The 16 row-group candidates of utterance bg (row groups are in class order): request, then
-// first-argmax.  Split so that the request can be issued before the fragment loads (vmcnt
-// retires in order: a wait for these then does not wait for the fragments behind them).
-struct Cand { float4 s[4]; int4 k[4]; };
-__device__ __forceinline__ void load_candidates(const ArModel &m, int bg, Cand &cd) {
-    const float4 *ps = (const float4 *)(m.cand_s + (size_t)bg * 16);
-    const int4 *pk = (const int4 *)(m.cand_k + (size_t)bg * 16);
+// The 16 row-group candidates of a decode slot (row groups are in class order): request, then
+// first-argmax, split so that the request can be issued early.  (A 4-lanes-per-slot variant that
+// combined by __shfl_xor made the wave-specialised kernel 5x slower on gfx950 -- measured, dropped.)
+struct Cand16 { float4 s[4]; int4 k[4]; };
+__device__ __forceinline__ void load_candidates16(const ArModel &m, int sg, Cand16 &cd) {
+    const float4 *ps = (const float4 *)(m.cand_s + (size_t)sg * 16);
+    const int4 *pk = (const int4 *)(m.cand_k + (size_t)sg * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { cd.s[q] = ps[q]; cd.k[q] = pk[q]; }
 }
-__device__ __forceinline__ int merge_candidates(const Cand &cd) {
+__device__ __forceinline__ int merge_candidates16(const Cand16 &cd) {
     float best = -INFINITY;
     int k = 0;
 #pragma unroll
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
         } else {
             const int bt = bt0 + g;
             const int sg = (bt < nbt ? bt : nbt - 1) * 16 + b;           // decode slot
-            Cand cd;
-            load_candidates(m, sg, cd);
+            Cand16 cd;
+            load_candidates16(m, sg, cd);
             const ArCall c = *cp;
             const int t = c.t_base + t_local;
             const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
                 if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
                 else if (first) x = m.n_cls / 2;
                 else {
-                    x = merge_candidates(cd);
+                    x = merge_candidates16(cd);
                     if (rg == 0 && u == 0) {                    // emit sample lt-1 (network_vocoder.py:78 output)
                         if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
                         if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
@@ -400,6 +400,129 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
             hout[hi] = (1.0f - z) * n + z * hold;
         }
+    }
+}
+
+// Large-batch GRU step (>= 4 utterance tiles in flight).  The wave-specialised kernel above re-reads
+// the state tile once per row group; at many tiles the per-CU L2 read rate (~65 GB/s) is the limit
+// (DESIGN "what bounds K7a").  Here one 1024-thread workgroup owns FOUR row groups and TWO tiles:
+// the two state tiles (2 x 57 KB) are staged ONCE in LDS and shared by the 16 waves
+// (wave = row group x K quarter), weights stay in registers: 342 KB per 8 (row group, tile) units
+// instead of 8 x 86 KB.  Grid = (Hr/16, ceil(nbt/2)).
+template <int SW>
+__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Hr = m.Hr;
+    float4 *hs = (float4 *)smem;                                             // [2][Hr*4] float4 = two state tiles
+    float (*red)[4][4][16][17] = (float (*)[4][4][16][17])(smem + (size_t)2 * Hr * 16 * sizeof(float));   // [tile][rg][kq]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = wave >> 2, kq = wave & 3;
+    const int rg = blockIdx.x * 4 + r, bt0 = blockIdx.y * 2, nb = nbt - bt0 < 2 ? nbt - bt0 : 2;
+    const size_t hsz = (size_t)nbt * Hr * 16;
+    const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
+    float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
+
+    // (1) cell-update inputs of (row group r, tile q = wave & 1) for waves with (wave & 2) == 0
+    const bool gate_wave = (wave & 2) == 0;                                  // 8 of 16 waves: (r, q) = (wave >> 2, wave & 1)
+    const int q = wave & 1, u = lane >> 4, b = lane & 15, unit = 4 * rg + u;
+    bool active = false, first = false;
+    float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
+    size_t hi = 0;
+    if (gate_wave) {
+        const int bt = bt0 + q;
+        const int sg = (bt < nbt ? bt : nbt - 1) * 16 + b;
+        Cand16 cd;                                                           // requested first: its 32 registers are
+        load_candidates16(m, sg, cd);                                        // dead again before the fragments arrive
+        const ArCall c = *cp;
+        const int t = c.t_base + t_local;
+        const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
+        const int lt = t - sl.t0;
+        const int xc = merge_candidates16(cd);
+        active = bt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
+        first = lt == 0;
+        if (active) {
+            int x;
+            if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
+            else if (first) x = m.n_cls / 2;
+            else {
+                x = xc;
+                if (rg == 0 && u == 0) {
+                    if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
+                    if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
+                }
+            }
+            x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
+            const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
+            const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
+            const float *bh = m.b_hh + unit;
+            hi = hl_index(Hr, sg, unit);
+            ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
+            gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
+            bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
+            hold = first ? 0.f : hin[hi];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (2) requests: this wave's weight fragment, this thread's share of state tile 0
+    // (state first: vmcnt retires in order, so the staging barrier then waits for the state only
+    // and the weight fragments keep streaming in underneath it)
+    const int t4 = Hr * 4;                                                   // float4 per state tile
+    const float4 *src = (const float4 *)hin + (size_t)bt0 * t4;
+    float4 st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
+        st[j] = i < t4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 wf[SW];
+    load_wfrag<SW>(m.Wf_hh, rg, 4, kq, lane, wf);
+    __builtin_amdgcn_sched_barrier(0);
+    // (3) stage tile 0, then request tile 1 so that it streams in underneath tile 0's MFMAs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
+        if (i < t4) hs[i] = st[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
+        st[j] = (nb > 1 && i < t4) ? src[t4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (4) W_hh h: this wave's row group and K quarter against tile 0, then tile 1
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        if (qq == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + 1024 * j;
+                if (i < t4) hs[t4 + i] = st[j];
+            }
+            __syncthreads();
+        }
+        const float4 *hp = hs + (size_t)qq * t4 + (size_t)kq * SW * 64 + lane;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            const float4 hv = hp[s * 64];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv.x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv.y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv.z, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv.w, a1, 0, 0, 0);
+        }
+        const f32x4 acc = a0 + a1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[qq][r][kq][(lane >> 4) * 4 + k][lane & 15] = acc[k];
+    }
+    __syncthreads();
+    // (5) cell update
+    if (active) {
+        const float gr = first ? 0.f : ((red[q][r][0][u][b] + red[q][r][1][u][b]) + red[q][r][2][u][b]) + red[q][r][3][u][b];
+        const float gz = first ? 0.f : ((red[q][r][0][4 + u][b] + red[q][r][1][4 + u][b]) + red[q][r][2][4 + u][b]) + red[q][r][3][4 + u][b];
+        const float gn = first ? 0.f : ((red[q][r][0][8 + u][b] + red[q][r][1][8 + u][b]) + red[q][r][2][8 + u][b]) + red[q][r][3][8 + u][b];
+        const float rr = sigmoidf_((ge0 + gc0) + (gr + bh0));
+        const float z = sigmoidf_((ge1 + gc1) + (gz + bh1));
+        const float n = tanhf((ge2 + gc2) + rr * (gn + bh2));
+        hout[hi] = (1.0f - z) * n + z * hold;
     }
 }
 
@@ -495,9 +618,12 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
     if (sl.row < 0) return;
     const int end = sl.t0 + sl.len;
     if (end <= c.t_base || end > c.t_base + c.S) return;
-    Cand cd;
-    load_candidates(m, sg, cd);
-    const int x = merge_candidates(cd);
+    float best = m.cand_s[(size_t)sg * 16];
+    int x = m.cand_k[(size_t)sg * 16];
+    for (int q = 1; q < 16; ++q) {
+        const float sc = m.cand_s[(size_t)sg * 16 + q];
+        if (sc > best) { best = sc; x = m.cand_k[(size_t)sg * 16 + q]; }
+    }
     if (c.wav) c.wav[(size_t)sl.row * c.Lout + sl.len - 1] = m.mulaw_tab[x];
     if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + sl.len - 1] = x;
 }
@@ -545,6 +671,8 @@ struct vqcpc_vocoder {
     DevBuf series, gi, out0, cond, gcond, hseq, har, a1, cand_s, cand_k, len;
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
+    int big_min_tiles = 8;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never)
+    bool big_attr_set = false;
     DevBuf slot_tab;
     std::map<int, hipGraphExec_t> graphs; // key: nbt
     hipStream_t cap_stream = nullptr;
@@ -668,6 +796,15 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         v->steps_per_graph = value;
         return VQCPC_OK;
     }
+    if (!strcmp(name, "big_min_tiles")) {
+        VQ_REQUIRE(value >= 0, "big_min_tiles must be >= 0");
+        if (value != v->big_min_tiles) {
+            for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+            v->graphs.clear();
+        }
+        v->big_min_tiles = value;
+        return VQCPC_OK;
+    }
     if (!strcmp(name, "slots")) {
         VQ_REQUIRE(value >= 0 && value <= 65536, "slots out of range");
         v->n_slots = value;
@@ -717,10 +854,23 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
 static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, hipStream_t s) {
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
+    // large-batch GRU kernel: >= big_min_tiles tiles in flight, Hr a multiple of 16, LDS fits
+    const size_t big_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 4 * 4 * 16 * 17 * sizeof(float);
+    const bool big = v->big_min_tiles > 0 && nbt >= v->big_min_tiles && v->d.Hr % 16 == 0 && big_lds <= 160 * 1024;
+    if (big && !v->big_attr_set) {
+        switch (SW) {
+#define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+#undef CASE
+            default: break;
+        }
+        v->big_attr_set = true;
+    }
     for (int i = 0; i < n; ++i) {
         switch (SW) {
 #define CASE(k) case k: \
             if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, i, nbt); \
+            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)v->call, i, nbt); \
             else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)v->call, i, nbt); \
             hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i, nbt); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
@@ -887,6 +1037,8 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     const ArModel m = v->last_model;
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
+    const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 4 * 4 * 16 * 17 * sizeof(float);
+    const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
             if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
@@ -896,6 +1048,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                 switch (SW) {
 #define CASE(k) case k: \
                     if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
+                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)v->call, 0, c.nbt); \
                     else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
                     else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)v->call, 0, c.nbt); break;
                     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
