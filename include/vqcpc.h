@@ -182,6 +182,24 @@ int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
  * Valid after the stream has been synchronised. */
 int vqcpc_vocoder_last_timing(vqcpc_vocoder *voc, float *loop_ms, int *n_steps);
 
+/* ------------------------------------------------------------------ Mel front-end ---- */
+
+/* Replaces wave_to_mel (preprocess.py:53-75; convert.py:54-70 is the same sequence): peak-normalise
+ * to 0.999, pre-emphasis (preprocess.py:16-17), centred STFT magnitude (periodic Hann `win`
+ * zero-padded to n_fft, reflect padding: librosa ^0.8), Slaney mel filterbank from fmin to sr/2,
+ * amplitude_to_db with top_db against the utterance maximum, / top_db + 1.  Defaults of the
+ * reference: config.py:103-112 (16000, 2048, 80, 160, 400, 50, 0.97, 80). */
+typedef struct vqcpc_melfront vqcpc_melfront;
+int vqcpc_melfront_create(int sr, int n_fft, int n_mels, int hop, int win, float fmin, float preemph,
+                          float top_db, vqcpc_melfront **out);
+void vqcpc_melfront_destroy(vqcpc_melfront *f);
+/* Frames of an n_samples utterance: 1 + n_samples / hop (centred STFT). */
+int vqcpc_melfront_frames(const vqcpc_melfront *f, int n_samples);
+/* wav DEVICE (B, Lmax) fp32, lens HOST (B) valid samples; mel DEVICE (B, n_mels, 1 + Lmax/hop) --
+ * the encoder's input layout; frames past an utterance's own length are zero. */
+int vqcpc_melfront_run(vqcpc_melfront *f, const float *wav, const int *lens, int B, int Lmax, float *mel,
+                       void *stream);
+
 /* Average wall time, in microseconds, of `reps` back-to-back launches of each per-sample kernel
  * of the decode loop on the state the last generate()/logits() call left (HIP events on
  * `stream`; synchronises it).  out_us[3] = {GRU step, fc1, fc2 + draw}.  Each figure includes

@@ -17,6 +17,7 @@ SYMBOLS = [
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
+    "vqcpc_melfront_create", "vqcpc_melfront_destroy", "vqcpc_melfront_frames", "vqcpc_melfront_run",
 ]
 
 
@@ -75,6 +76,11 @@ def load():
     lib.vqcpc_vocoder_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.vqcpc_vocoder_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.vqcpc_vocoder_kernel_times.argtypes = [vp, i32, C.POINTER(C.c_float), vp]
+    lib.vqcpc_melfront_create.argtypes = [i32, i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]
+    lib.vqcpc_melfront_destroy.argtypes = [vp]
+    lib.vqcpc_melfront_destroy.restype = None
+    lib.vqcpc_melfront_frames.argtypes = [vp, i32]
+    lib.vqcpc_melfront_run.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, vp]
     _lib = lib
     return lib
 

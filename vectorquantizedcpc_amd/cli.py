@@ -7,8 +7,9 @@
                                                  [--cpc-checkpoint .. --vocoder-checkpoint .. | --random-init] [--seed 13]
 
 ``encode`` mirrors ``encode.py:14-67``.  ``convert`` mirrors ``convert.py:17-83`` from the mel onwards: inputs are
-``<in_dir>/<utterance>.mel.npy`` (the librosa front-end of ``convert.py:54-70`` and the loudness
-re-normalisation of ``:79-80`` are CPU steps outside the hot path).  Utterances are batched by the
+``<in_dir>/<utterance>.mel.npy`` or, if absent, ``<utterance>.wav`` (16 kHz) run through the HIP mel
+front-end (``preprocess.wave_to_mel`` = ``convert.py:54-70``); the loudness re-normalisation of
+``convert.py:79-80`` (pyloudnorm, CPU) is not reproduced.  Utterances are batched by the
 length-bucketed drivers; every output equals the batch-1 result.
 """
 import argparse
@@ -17,7 +18,7 @@ from pathlib import Path
 
 import torch
 
-from . import ConfEncoder, ConfVocoder, Encoder, Vocoder, driver, io, synth
+from . import ConfEncoder, ConfVocoder, Encoder, Vocoder, driver, io, preprocess, synth
 
 
 def _models(args, need_vocoder):
@@ -63,7 +64,12 @@ def convert_dataset(args) -> int:
     in_dir, out_dir = Path(args.in_dir), Path(args.out_dir)
     out_dir.mkdir(exist_ok=True, parents=True)
     enc, voc = _models(args, need_vocoder=True)
-    mels = [io.load_mel(in_dir / p) for p, _, _ in items]
+    mels = []
+    for p, _, _ in items:
+        if (in_dir / p).with_suffix(".mel.npy").exists():
+            mels.append(io.load_mel(in_dir / p))
+        else:                                                  # convert.py:54-70: wav -> log-mel, on the GPU
+            mels.append(preprocess.wave_to_mel(io.load_wav(in_dir / p).to(args.device)))
     wavs = driver.convert_utterances(enc, voc, mels, [s for _, s, _ in items], seed=args.seed, max_batch=args.max_batch)
     for (_, _, name), w in zip(items, wavs):
         io.save_wav(out_dir / name, w, 16000)

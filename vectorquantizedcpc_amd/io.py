@@ -28,6 +28,20 @@ def load_mel(path) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 
+def load_wav(path, sr: int = 16000) -> torch.Tensor:
+    """16 kHz mono waveform as float32 in [-1, 1] (``convert.py:54-56`` loads with librosa at cfg sr;
+    resampling is not done here: a file at another rate is an error)."""
+    from scipy.io import wavfile
+    rate, a = wavfile.read(str(Path(path).with_suffix(".wav")))
+    if rate != sr:
+        raise ValueError(f"{path}: sample rate {rate}, expected {sr} (resample offline)")
+    if a.ndim > 1:
+        a = a.mean(axis=1)
+    if a.dtype.kind == "i":
+        a = a.astype(np.float32) / float(np.iinfo(a.dtype).max + 1)
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
 def save_frames_text(path, frames) -> None:
     """One row per frame, ``%.16f`` (``encode.py:50-52``)."""
     a = frames.detach().cpu().numpy() if hasattr(frames, "detach") else np.asarray(frames)
