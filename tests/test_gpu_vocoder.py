@@ -152,3 +152,20 @@ def test_continuous_batching_equals_static_batches():
             voc.set_option("slots", 0)
         assert torch.equal(m, ref_m) and torch.equal(w, ref_w), slots
     assert int((ref_m[1, 320:] != 0).sum()) == 0 and int((ref_m[0] != 0).sum()) > 1000
+
+
+def test_error_surface_like_nn_embedding():
+    voc, _ = vocoder()
+    z = torch.zeros(1, 2, dtype=torch.long, device="cuda")
+    with pytest.raises(IndexError):
+        voc.generate(torch.full((1, 2), 512, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))
+    with pytest.raises(IndexError):
+        voc.generate(z, torch.tensor([102], device="cuda"))
+    with pytest.raises(IndexError):
+        voc(torch.full((1, 10), 256, device="cuda"), z, torch.zeros(1, dtype=torch.long, device="cuda"))
+    with pytest.raises(RuntimeError):
+        voc.generate(z, torch.zeros(2, dtype=torch.long, device="cuda"))
+    with pytest.raises(RuntimeError):
+        voc.generate(z.float(), torch.zeros(1, dtype=torch.long, device="cuda"))
+    with pytest.raises(RuntimeError):
+        voc(torch.zeros(1, 641, dtype=torch.long, device="cuda"), z, torch.zeros(1, dtype=torch.long, device="cuda"))

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Encoder-only loop for rocprofv3 (BASELINE configs[1]: 64 x 80 x 128 mel -> 4096 code frames)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vectorquantizedcpc_amd as V
+from vectorquantizedcpc_amd import synth
+
+enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
+enc.load_state_dict(synth.encoder_state_dict())
+enc = enc.cuda().eval()
+mel = synth.mel("bench/c2", 64, 128).cuda()
+want_c = len(sys.argv) > 1 and sys.argv[1] == "context"
+for _ in range(3):
+    enc.encode(mel) if want_c else enc.encode_indices(mel)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+reps = 50
+for _ in range(reps):
+    enc.encode(mel) if want_c else enc.encode_indices(mel)
+torch.cuda.synchronize()
+print(f"{'encode' if want_c else 'encode_indices'}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per call")

@@ -75,10 +75,9 @@ struct GemmP {
 };
 
 template <int AMODE>
-__device__ __forceinline__ void load_a_tile(const GemmP &p, float (*As)[GT_LD], int m0, int k0, int tid) {
+__device__ __forceinline__ void fetch_a(const GemmP &p, int m0, int k0, int tid, float (&v)[8]) {
     const int row = tid >> 2, kq = (tid & 3) * 8;
     const int m = m0 + row;
-    float v[8];
     if (AMODE == 0) {
         if (m < p.M) {
             const float4 *src = (const float4 *)(p.A + (size_t)m * p.lda + k0 + kq);
@@ -101,16 +100,17 @@ __device__ __forceinline__ void load_a_tile(const GemmP &p, float (*As)[GT_LD], 
             v[i] = (m < p.M && ti >= 0 && ti < p.T) ? p.x[((size_t)b * p.C + c) * p.T + ti] : 0.f;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) As[kq + i][row] = v[i];
 }
-
-__device__ __forceinline__ void load_w_tile(const GemmP &p, float (*Ws)[GT_LD], int n0, int k0, int tid) {
+__device__ __forceinline__ void fetch_w(const GemmP &p, int n0, int k0, int tid, float (&v)[8]) {
     const int row = tid >> 2, kq = (tid & 3) * 8;
     const float4 *src = (const float4 *)(p.W + (size_t)(n0 + row) * p.K + k0 + kq);
     float4 a = src[0], b = src[1];
-    Ws[kq + 0][row] = a.x; Ws[kq + 1][row] = a.y; Ws[kq + 2][row] = a.z; Ws[kq + 3][row] = a.w;
-    Ws[kq + 4][row] = b.x; Ws[kq + 5][row] = b.y; Ws[kq + 6][row] = b.z; Ws[kq + 7][row] = b.w;
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void stage(float (*T)[GT_LD], int tid, const float (&v)[8]) {
+    const int row = tid >> 2, kq = (tid & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[kq + i][row] = v[i];
 }
 
 template <int AMODE, int EPI>
@@ -127,11 +127,19 @@ __global__ __launch_bounds__(256) void gemm_chain_kernel(GemmP p) {
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; tot[r] = 0.f; }
     bool first = true;
 
+    // register prefetch: the next k tile's global loads fly underneath this tile's MFMAs
+    float va[8], vw[8];
+    fetch_a<AMODE>(p, m0, 0, tid, va);
+    fetch_w(p, n0, 0, tid, vw);
     for (int k0 = 0; k0 < p.K; k0 += GT_BK) {
         __syncthreads();
-        load_a_tile<AMODE>(p, As, m0, k0, tid);
-        load_w_tile(p, Ws, n0, k0, tid);
+        stage(As, tid, va);
+        stage(Ws, tid, vw);
         __syncthreads();
+        if (k0 + GT_BK < p.K) {
+            fetch_a<AMODE>(p, m0, k0 + GT_BK, tid, va);
+            fetch_w(p, n0, k0 + GT_BK, tid, vw);
+        }
 #pragma unroll
         for (int kk = 0; kk < GT_BK / 2; ++kk) {
             const float a = As[2 * kk + half][wm * 32 + li];

@@ -162,13 +162,19 @@ class Vocoder(nn.Module):
         return tuple(float(v) for v in out)
 
     # ------------------------------------------------------------------ reference surface
-    @staticmethod
-    def _prep(z: Tensor, speaker: Tensor):
+    def _prep(self, z: Tensor, speaker: Tensor):
         _lib.require_cuda(z, "z")
         if z.dim() != 2 or speaker.dim() != 1 or speaker.size(0) != z.size(0):
             raise RuntimeError(f"expected z (B, T') and speaker (B), got {tuple(z.shape)} and {tuple(speaker.shape)}")
-        return (z.detach().to(torch.int64).contiguous(),
-                speaker.detach().to(device=z.device, dtype=torch.int64).contiguous())
+        if z.is_floating_point() or speaker.is_floating_point():
+            raise RuntimeError("z and speaker must be integer tensors (nn.Embedding indices, network_vocoder.py:73,75)")
+        z = z.detach().to(torch.int64).contiguous()
+        speaker = speaker.detach().to(device=z.device, dtype=torch.int64).contiguous()
+        # nn.Embedding raises on an out-of-range index (network_vocoder.py:73,75); so do we (one tiny sync)
+        lo = torch.stack((z.min(), speaker.min())).min().item()
+        if lo < 0 or z.max().item() >= self.conf.size_i_codebook or speaker.max().item() >= self.conf.n_speakers:
+            raise IndexError("index out of range in self")
+        return z, speaker
 
     @torch.no_grad()
     def generate(self, z: Tensor, speaker: Tensor, *, n_codes=None, seed=None, utt_base=None, utt_ids=None,
@@ -210,7 +216,13 @@ class Vocoder(nn.Module):
         z, speaker = self._prep(z, speaker)
         x = x.detach().to(device=z.device, dtype=torch.int64).contiguous()
         B, Tc = z.shape
+        if x.dim() != 2 or x.size(0) != B:
+            raise RuntimeError(f"expected x (B, T_s), got {tuple(x.shape)}")
         Ts = x.size(1)
+        if Ts > 2 * self.conf.rnnms.upsampling_t * Tc:
+            raise RuntimeError("x is longer than the conditioning series covers")
+        if x.min().item() < 0 or x.max().item() >= 2 ** self.conf.rnnms.bits_mu_law:
+            raise IndexError("index out of range in self")
         logits = torch.empty(B, Ts, 2 ** self.conf.rnnms.bits_mu_law, device=z.device)
         with torch.cuda.device(z.device):
             _lib.check(_lib.load().vqcpc_vocoder_logits(self._native(), x.data_ptr(), z.data_ptr(), speaker.data_ptr(),
