@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void seq_step_kernel(SeqP p, int step) {
     float *hout = p.hbuf + ((size_t)((step + 1) & 1) * p.ndir + dir) * hsz;
     float4 wf[SW];
     load_wfrag<SW>(p.Wf + (size_t)dir * (H / 4) * (H / 16) * 64 * 4, rg, 4, wave, lane, wf);
-    for (int bt = 0; bt < p.nbt; ++bt) {
+    {
+        const int bt = blockIdx.z;                 // one utterance tile per workgroup
         const f32x4 acc = mv16<SW>(wf, hin, H, bt, wave, lane);
         const float v = reduce4(red, acc, wave, lane, tid);
         gate[tid >> 4][tid & 15] = v;
@@ -156,14 +157,13 @@ __global__ __launch_bounds__(256) void seq_step_kernel(SeqP p, int step) {
                 p.out[((size_t)bg * p.T + tpos) * (p.ndir * H) + (size_t)dir * H + unit] = hn;
             }
         }
-        __syncthreads();
     }
 }
 
 template <int G>
 static int launch_seq(const SeqP &p, int step, hipStream_t s) {
     const int SW = p.H / 64;
-    dim3 grid(p.H / 4, p.ndir), blk(256);
+    dim3 grid(p.H / 4, p.ndir, p.nbt), blk(256);
     switch (SW) {
 #define CASE(n) case n: hipLaunchKernelGGL((seq_step_kernel<G, n>), grid, blk, 0, s, p, step); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
