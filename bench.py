@@ -199,9 +199,10 @@ def main():
     value = samples / dt
     loop_ms, n_loop = voc.last_timing()                       # HIP events around the last decode loop
     step_us = loop_ms * 1e3 / max(n_loop, 1)
-    gru_us, fc1_us, fc2_us = voc.kernel_times(2000)           # HIP events around back-to-back launches
-    # dominant kernel = the GRU step: algorithmic FLOP per launch = W_hh mat-vec for every utterance
-    gru_flop = 2.0 * 2408448 * Bp
+    gru_us, fc1_us, fc2_us, per_launch = voc.kernel_times(2000)   # HIP events around back-to-back launches
+    per_launch = min(int(per_launch), Bp)                     # utterances one launch covers (tile group)
+    # dominant kernel = the GRU step: algorithmic FLOP per launch = W_hh mat-vec for every utterance it covers
+    gru_flop = 2.0 * 2408448 * per_launch
     achieved = gru_flop / (gru_us * 1e-6) / 1e12
     step_tflops = FLOP_PER_SAMPLE * Bp / (step_us * 1e-6) / 1e12
     # HBM-side bytes per launch of that kernel: collected offline with rocprofv3 --pmc (separate
@@ -209,12 +210,12 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pmc.get("utterances") == Bp:
+        if pmc.get("utterances") == per_launch:
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
-    gru_bytes = 4.0 * (2408448 + Bp * (2 * 896 + 2 * 3 * 896))
+    gru_bytes = 4.0 * (2408448 + per_launch * (2 * 896 + 2 * 3 * 896))
 
     result = {
         "metric": "audio samples/sec (WaveRNN-style decode, convert.py path: encode + generate)",
@@ -232,7 +233,7 @@ def main():
                      "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; mostly Infinity-Cache hits)",
                      "algorithmic_bytes_per_launch": gru_bytes,
-                     "flop_per_launch": gru_flop, "avg_launch_us": gru_us,
+                     "flop_per_launch": gru_flop, "avg_launch_us": gru_us, "utterances_per_launch": per_launch,
                      "how": "HIP events on the launch stream around 2000 back-to-back launches (includes the "
                             "~1.5 us dependent-launch boundary)",
                      "other_kernels_us": {"ar_fc1_kernel": fc1_us, "ar_fc2_kernel": fc2_us},

@@ -174,7 +174,8 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
  * slots: continuous batching -- decode with this many slots, each running utterances back to back
  * (0 = one slot per utterance).  big_min_tiles: utterance tiles (of 16) from which the LDS-staged
- * large-batch GRU kernel is used (default 8, 0 = never). */
+ * large-batch GRU kernel is used (default 8, 0 = never).  two_groups: run calls of 3..big_min_tiles-1
+ * tiles as two independent tile groups on two streams (default 1). */
 int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
 
 /* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call
@@ -202,7 +203,8 @@ int vqcpc_melfront_run(vqcpc_melfront *f, const float *wav, const int *lens, int
 
 /* Average wall time, in microseconds, of `reps` back-to-back launches of each per-sample kernel
  * of the decode loop on the state the last generate()/logits() call left (HIP events on
- * `stream`; synchronises it).  out_us[3] = {GRU step, fc1, fc2 + draw}.  Each figure includes
+ * `stream`; synchronises it).  out_us[4] = {GRU step, fc1, fc2 + draw, decode slots one launch
+ * covers (a call of 33..112 utterances runs as two independent tile groups)}.  Each time includes
  * this chip's ~1.5 us dependent-launch boundary. */
 int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 

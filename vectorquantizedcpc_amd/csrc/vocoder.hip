@@ -608,6 +608,15 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
 
 __global__ void ar_advance_kernel(ArCall *c, int n) { c->t_base += n; }
 
+// Bounded delay (~cycles shader clocks): offsets the second tile group by about half a sample step.
+__global__ void ar_delay_kernel(int cycles) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 4096; ++i) {
+        if ((long long)(__builtin_amdgcn_s_memtime() - t0) >= cycles) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // End of every replay: an utterance whose last sample fell inside this replay still has that sample
 // only as candidates (the next GRU step would have merged them): emit it before the slot is reused.
 __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
@@ -667,19 +676,27 @@ struct vqcpc_vocoder {
     float *w_cond = nullptr, *b_ih = nullptr, *Gemb = nullptr;
     float *Wf_hh = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
     float *mulaw_tab = nullptr;
-    ArCall *call = nullptr;              // device
-    DevBuf series, gi, out0, cond, gcond, hseq, har, a1, cand_s, cand_k, len;
+    // A decode call runs as 1 or 2 independent TILE GROUPS (disjoint utterance tiles, own state,
+    // own call record, own captured graph).  Two groups run on two streams so that one group's GRU
+    // step overlaps the other's fc1/fc2; there is no edge between them inside a graph.
+    struct Group {
+        ArCall *call = nullptr;          // device
+        DevBuf har, a1, cand_s, cand_k, slot_tab;
+        std::map<int, hipGraphExec_t> graphs;   // key: tiles in the group
+        const void *baked[4] = {nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
+    } grp[2];
+    int two_groups = 1;                  // 0 = always one group
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf series, gi, out0, cond, gcond, hseq, len;
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
     int big_min_tiles = 8;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never)
     bool big_attr_set = false;
-    DevBuf slot_tab;
-    std::map<int, hipGraphExec_t> graphs; // key: nbt
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_steps = 0;
-    const void *baked[4] = {nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
-    ArCall last_call{};                  // host copies of the last decode call (kernel timing)
+    ArCall last_call{};                  // host copies of group 0 of the last decode call (kernel timing)
     ArModel last_model{};
     bool have_last = false;
 };
@@ -692,14 +709,20 @@ static int dcopy(float **dst, const float *src, size_t n) {
 
 extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (!v) return;
-    for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto &g : v->grp) {
+        for (auto &kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
+        if (g.call) (void)hipFree(g.call);
+        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab};
+        for (DevBuf *b : gb) b->release();
+    }
+    if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
+    if (v->ev_fork) (void)hipEventDestroy(v->ev_fork);
+    if (v->ev_join) (void)hipEventDestroy(v->ev_join);
     float *ptrs[] = {v->code_emb, v->spk_emb, v->p_wih[0], v->p_wih[1], v->p_bih[0], v->p_bih[1], v->p_bhh[0],
                      v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh, v->b_hh,
                      v->Wf_fc1, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
     for (float *p : ptrs) if (p) (void)hipFree(p);
-    if (v->call) (void)hipFree(v->call);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->har, &v->a1, &v->cand_s, &v->cand_k, &v->len,
-                      &v->slot_tab};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -758,7 +781,10 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     }
     HIP_TRY(hipMalloc((void **)&v->mulaw_tab, tab.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(v->mulaw_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&v->call, sizeof(ArCall)));
+    for (auto &g : v->grp) HIP_TRY(hipMalloc((void **)&g.call, sizeof(ArCall)));
+    HIP_TRY(hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&v->ev0));
     HIP_TRY(hipEventCreate(&v->ev1));
@@ -784,27 +810,29 @@ extern "C" int vqcpc_vocoder_create(const vqcpc_vocoder_weights *w, vqcpc_vocode
     return VQCPC_OK;
 }
 
+static void clear_graphs(vqcpc_vocoder *v) {
+    for (auto &g : v->grp) {
+        for (auto &kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
+        g.graphs.clear();
+    }
+}
+
 extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int value) {
     VQ_REQUIRE(v && name, "vqcpc_vocoder_set_option: null argument");
     if (!strcmp(name, "use_graph")) { v->use_graph = value != 0; return VQCPC_OK; }
     if (!strcmp(name, "steps_per_graph")) {
         VQ_REQUIRE(value > 0 && value <= 4096 && value % 2 == 0, "steps_per_graph must be even and in [2, 4096]");
-        if (value != v->steps_per_graph) {
-            for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
-            v->graphs.clear();
-        }
+        if (value != v->steps_per_graph) clear_graphs(v);
         v->steps_per_graph = value;
         return VQCPC_OK;
     }
     if (!strcmp(name, "big_min_tiles")) {
         VQ_REQUIRE(value >= 0, "big_min_tiles must be >= 0");
-        if (value != v->big_min_tiles) {
-            for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
-            v->graphs.clear();
-        }
+        if (value != v->big_min_tiles) clear_graphs(v);
         v->big_min_tiles = value;
         return VQCPC_OK;
     }
+    if (!strcmp(name, "two_groups")) { v->two_groups = value != 0; return VQCPC_OK; }
     if (!strcmp(name, "slots")) {
         VQ_REQUIRE(value >= 0 && value <= 65536, "slots out of range");
         v->n_slots = value;
@@ -851,7 +879,7 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     return VQCPC_OK;
 }
 
-static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, hipStream_t s) {
+static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int nbt, int n, hipStream_t s) {
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
     // large-batch GRU kernel: >= big_min_tiles tiles in flight, Hr a multiple of 16, LDS fits
@@ -869,18 +897,18 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, int nbt, int n, h
     for (int i = 0; i < n; ++i) {
         switch (SW) {
 #define CASE(k) case k: \
-            if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, i, nbt); \
-            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)v->call, i, nbt); \
-            else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)v->call, i, nbt); \
-            hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i, nbt); break;
+            if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt); \
+            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt); \
+            else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
+            hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
             default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
         }
-        hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)v->call, i);
+        hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
     }
-    hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)v->call);
-    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, v->call, n);
+    hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
+    hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, call, n);
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
 }
@@ -912,7 +940,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // Decode-slot schedule (continuous batching): longest utterance first onto the slot that frees
     // up first; an utterance starts at a replay boundary.  n_slots >= B: everything starts at 0.
     int n_slots = (v->n_slots > 0 && v->n_slots < B && !inputs) ? v->n_slots : B;
-    const int nbt = (n_slots + 15) / 16, Sp = nbt * 16;
+    const int nbt = (n_slots + 15) / 16;
     std::vector<int> order(B);
     for (int b = 0; b < B; ++b) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[Bp + a] > lens[Bp + b]; });
@@ -930,15 +958,32 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         total = slot_end[best] > total ? slot_end[best] : total;
     }
     VQ_REQUIRE(total < (1L << 30), "vocoder: schedule too long");
-    const int max_t = (int)total, n_rep = max_t / S;
-    std::vector<ArSlot> table((size_t)(n_rep > 0 ? n_rep : 1) * Sp, ArSlot{-1, 0, 0, 0u});
-    for (const Seg &g : segs)
-        for (int r = g.t0 / S; r < (g.t0 + g.len + S - 1) / S; ++r)
-            table[(size_t)r * Sp + g.slot] = ArSlot{g.row, g.t0, g.len, utt[g.row]};
+    const int max_t = (int)total;
+    // Tile groups: 3..big_min_tiles-1 tiles split in two.  (Measured: 2 x 16 utterances is slower than one
+    // group of 32 -- the chip retires only ~0.43 dependent launches per us across queues -- while
+    // 2 x 32 runs at 14.5 us per sample against 17.3 us for one group of 64.)
+    const bool split = v->two_groups && v->use_graph && nbt >= 3 && !(v->big_min_tiles > 0 && nbt >= v->big_min_tiles);
+    const int n_grp = split ? 2 : 1;
+    const int tiles[2] = {split ? (nbt + 1) / 2 : nbt, split ? nbt / 2 : 0};
+    const int slot0[2] = {0, tiles[0] * 16};
     TRY(v->len.reserve(lens.size() * sizeof(int)));
-    TRY(v->slot_tab.reserve(table.size() * sizeof(ArSlot)));
     HIP_TRY(hipMemcpyAsync(v->len.p, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(v->slot_tab.p, table.data(), table.size() * sizeof(ArSlot), hipMemcpyHostToDevice, s));
+    std::vector<ArSlot> table[2];
+    int rep[2] = {0, 0}, gmax[2] = {0, 0};
+    for (int g = 0; g < n_grp; ++g) {
+        const int Spg = tiles[g] * 16;
+        long end = 0;
+        for (int q = slot0[g]; q < slot0[g] + Spg && q < n_slots; ++q) end = slot_end[q] > end ? slot_end[q] : end;
+        gmax[g] = (int)end; rep[g] = gmax[g] / S;
+        table[g].assign((size_t)(rep[g] > 0 ? rep[g] : 1) * Spg, ArSlot{-1, 0, 0, 0u});
+        for (const Seg &sg : segs) {
+            if (sg.slot < slot0[g] || sg.slot >= slot0[g] + Spg) continue;
+            for (int r = sg.t0 / S; r < (sg.t0 + sg.len + S - 1) / S; ++r)
+                table[g][(size_t)r * Spg + (sg.slot - slot0[g])] = ArSlot{sg.row, sg.t0, sg.len, utt[sg.row]};
+        }
+        TRY(v->grp[g].slot_tab.reserve(table[g].size() * sizeof(ArSlot)));
+        HIP_TRY(hipMemcpyAsync(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));     // host vectors above die with this frame
     const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
 
@@ -947,60 +992,84 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     TRY(run_condition(v, idx, spk, B, Tc, frames_dev, v->cond.as<float>(), s));
     TRY(v->gcond.reserve(rows * 3 * Hr * sizeof(float)));
     TRY(vq_gemm_chain(v->cond.as<float>(), dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)rows, 3 * Hr, dl, dl, s));
-
-    const size_t hsz = (size_t)nbt * Hr * 16 * sizeof(float);
-    TRY(v->har.reserve(2 * hsz));
-    TRY(v->a1.reserve((size_t)nbt * d.Hf * 16 * sizeof(float)));
-    TRY(v->cand_s.reserve((size_t)Sp * 16 * sizeof(float)));
-    TRY(v->cand_k.reserve((size_t)Sp * 16 * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(v->har.p, 0, 2 * hsz, s));
-    HIP_TRY(hipMemsetAsync(v->cand_s.p, 0, (size_t)Sp * 16 * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(v->cand_k.p, 0, (size_t)Sp * 16 * sizeof(int), s));
     if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
-    ArCall c{};
-    c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
-    c.slots = v->slot_tab.as<ArSlot>(); c.S = S; c.Sp = Sp;
-    c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = max_t; c.nbt = nbt; c.seed = seed; c.t_base = 0;
-    HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));     // c is a stack-lifetime host buffer
-
-    ArModel m{};
-    m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.b_fc1 = v->b_fc1;
-    m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
-    m.hbuf = v->har.as<float>(); m.a1 = v->a1.as<float>(); m.cand_s = v->cand_s.as<float>(); m.cand_k = v->cand_k.as<int>();
-    m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
+    ArCall calls[2];
+    ArModel models[2];
+    for (int g = 0; g < n_grp; ++g) {
+        auto &G = v->grp[g];
+        const int nb = tiles[g], Spg = nb * 16;
+        const size_t hsz = (size_t)nb * Hr * 16 * sizeof(float);
+        TRY(G.har.reserve(2 * hsz));
+        TRY(G.a1.reserve((size_t)nb * d.Hf * 16 * sizeof(float)));
+        TRY(G.cand_s.reserve((size_t)Spg * 16 * sizeof(float)));
+        TRY(G.cand_k.reserve((size_t)Spg * 16 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(G.har.p, 0, 2 * hsz, s));
+        HIP_TRY(hipMemsetAsync(G.cand_s.p, 0, (size_t)Spg * 16 * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(G.cand_k.p, 0, (size_t)Spg * 16 * sizeof(int), s));
+        ArCall &c = calls[g];
+        c = ArCall{};
+        c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
+        c.slots = G.slot_tab.as<ArSlot>(); c.S = S; c.Sp = Spg;
+        c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = gmax[g]; c.nbt = nb; c.seed = seed; c.t_base = 0;
+        HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
+        ArModel &m = models[g];
+        m = ArModel{};
+        m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.b_fc1 = v->b_fc1;
+        m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
+        m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>();
+        m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
+    }
+    HIP_TRY(hipStreamSynchronize(s));     // calls[] is a stack-lifetime host buffer
 
     HIP_TRY(hipEventRecord(v->ev0, s));
     if (v->use_graph) {
-        // The graph bakes ArModel (buffer pointers): drop cached graphs if a workspace moved.
-        const void *now[4] = {v->har.p, v->a1.p, v->cand_s.p, v->cand_k.p};
-        if (memcmp(v->baked, now, sizeof now) != 0) {
-            for (auto &kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
-            v->graphs.clear();
-            memcpy(v->baked, now, sizeof now);
+        hipGraphExec_t exec[2] = {nullptr, nullptr};
+        for (int g = 0; g < n_grp; ++g) {
+            auto &G = v->grp[g];
+            // a graph bakes its ArModel (buffer pointers): drop cached graphs if a workspace moved
+            const void *now[4] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p};
+            if (memcmp(G.baked, now, sizeof now) != 0) {
+                for (auto &kv : G.graphs) (void)hipGraphExecDestroy(kv.second);
+                G.graphs.clear();
+                memcpy(G.baked, now, sizeof now);
+            }
+            auto it = G.graphs.find(tiles[g]);
+            if (it == G.graphs.end()) {
+                hipGraph_t gr = nullptr;
+                hipGraphExec_t ge = nullptr;
+                HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
+                int rc = launch_ar_steps(v, models[g], G.call, tiles[g], S, v->cap_stream);
+                hipError_t e = hipStreamEndCapture(v->cap_stream, &gr);
+                if (rc != VQCPC_OK) return rc;
+                HIP_TRY(e);
+                HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+                HIP_TRY(hipGraphDestroy(gr));
+                it = G.graphs.emplace(tiles[g], ge).first;
+            }
+            exec[g] = it->second;
         }
-        auto it = v->graphs.find(nbt);
-        if (it == v->graphs.end()) {
-            hipGraph_t g = nullptr;
-            hipGraphExec_t ge = nullptr;
-            HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = launch_ar_steps(v, m, nbt, S, v->cap_stream);
-            hipError_t e = hipStreamEndCapture(v->cap_stream, &g);
-            if (rc != VQCPC_OK) return rc;
-            HIP_TRY(e);
-            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            HIP_TRY(hipGraphDestroy(g));
-            it = v->graphs.emplace(nbt, ge).first;
+        if (n_grp == 2) {                 // group 1 runs on the side stream, half a sample step out of phase
+            HIP_TRY(hipEventRecord(v->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(v->side_stream, v->ev_fork, 0));
+            hipLaunchKernelGGL(ar_delay_kernel, dim3(1), dim3(1), 0, v->side_stream, 12000);
         }
-        for (int t0 = 0; t0 < max_t; t0 += S) HIP_TRY(hipGraphLaunch(it->second, s));
+        const int nr = rep[0] > rep[1] ? rep[0] : rep[1];
+        for (int r = 0; r < nr; ++r) {
+            if (r < rep[0]) HIP_TRY(hipGraphLaunch(exec[0], s));
+            if (n_grp == 2 && r < rep[1]) HIP_TRY(hipGraphLaunch(exec[1], v->side_stream));
+        }
+        if (n_grp == 2) {
+            HIP_TRY(hipEventRecord(v->ev_join, v->side_stream));
+            HIP_TRY(hipStreamWaitEvent(s, v->ev_join, 0));
+        }
     } else {
-        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, m, nbt, S, s));
+        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, models[0], v->grp[0].call, nbt, S, s));
     }
     HIP_TRY(hipEventRecord(v->ev1, s));
     v->last_steps = max_t;
-    v->last_call = c; v->last_model = m; v->have_last = true;
+    v->last_call = calls[0]; v->last_model = models[0]; v->have_last = true;
     return VQCPC_OK;
 }
 
@@ -1032,7 +1101,8 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     ArCall c = v->last_call;
     c.t_base = 1;                        // a mid-utterance step (t = 1: candidates are merged, Gemb gathered)
     c.wav = nullptr; c.mulaw = nullptr; c.logits = nullptr;
-    HIP_TRY(hipMemcpyAsync(v->call, &c, sizeof c, hipMemcpyHostToDevice, s));
+    ArCall *call = v->grp[0].call;
+    HIP_TRY(hipMemcpyAsync(call, &c, sizeof c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     const ArModel m = v->last_model;
     const int SW = v->d.Hr / 64;
@@ -1044,13 +1114,13 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
             if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
             const int n = pass == 0 ? 20 : reps;
             for (int i = 0; i < n; ++i) {
-                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)v->call, 0); continue; }
+                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
-                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)v->call, 0, c.nbt); \
-                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)v->call, 0, c.nbt); \
-                    else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)v->call, 0, c.nbt); break;
+                    if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); break;
                     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
                     default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
@@ -1063,6 +1133,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
         HIP_TRY(hipEventElapsedTime(&ms, v->ev0, v->ev1));
         out_us[which] = ms * 1e3f / (float)reps;
     }
+    out_us[3] = (float)(c.nbt * 16);       // decode slots one launch of the timed configuration covers
     return VQCPC_OK;
 }
 

@@ -156,8 +156,8 @@ class Vocoder(nn.Module):
         return ms.value, n.value
 
     def kernel_times(self, reps: int = 1000):
-        """Average microseconds per launch of (GRU step, fc1, fc2 + draw): ``vqcpc_vocoder_kernel_times``."""
-        out = (C.c_float * 3)()
+        """(us GRU step, us fc1, us fc2 + draw, decode slots per launch): ``vqcpc_vocoder_kernel_times``."""
+        out = (C.c_float * 4)()
         _lib.check(_lib.load().vqcpc_vocoder_kernel_times(self._native(), int(reps), out, _lib.current_stream()))
         return tuple(float(v) for v in out)
 
