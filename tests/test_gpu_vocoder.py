@@ -169,3 +169,32 @@ def test_error_surface_like_nn_embedding():
         voc.generate(z.float(), torch.zeros(1, dtype=torch.long, device="cuda"))
     with pytest.raises(RuntimeError):
         voc(torch.zeros(1, 641, dtype=torch.long, device="cuda"), z, torch.zeros(1, dtype=torch.long, device="cuda"))
+
+
+def test_tile_groups_and_large_batch_kernel_are_bit_identical():
+    """40 utterances = 3 tiles: one group vs two groups on two streams vs the LDS-staged large-batch
+    kernel, with continuous batching on top -- all the same bits (tiles are independent MFMA columns)."""
+    voc, _ = vocoder()
+    B = 40
+    z = synth.randint("tg/z", (B, 3), 512).cuda()
+    spk = (torch.arange(B) % 102).cuda()
+    n_codes = [1 + (i % 3) for i in range(B)]
+    ids = list(range(100, 100 + B))
+    outs = {}
+    try:
+        for name, opts in (("one_group", {"two_groups": 0, "big_min_tiles": 0}),
+                           ("two_groups", {"two_groups": 1, "big_min_tiles": 0}),
+                           ("big_kernel", {"two_groups": 0, "big_min_tiles": 2}),
+                           ("two_groups_36_slots", {"two_groups": 1, "big_min_tiles": 0, "slots": 36})):
+            for k, val in opts.items():
+                voc.set_option(k, val)
+            outs[name] = voc.generate(z, spk, n_codes=n_codes, seed=9, utt_ids=ids, return_mulaw=True)[1]
+            voc.set_option("slots", 0)
+    finally:
+        voc.set_option("two_groups", 1)
+        voc.set_option("big_min_tiles", 8)
+        voc.set_option("slots", 0)
+    ref = outs["one_group"]
+    assert int((ref != 0).sum()) > 10000
+    for name, m in outs.items():
+        assert torch.equal(m, ref), name
