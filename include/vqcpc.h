@@ -13,7 +13,11 @@
  *    contiguous, borrowed for the duration of the enqueued work.  HOST pointers are read
  *    before the call returns.
  *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
- *    stream).  No call synchronises the device except where stated.
+ *    stream).  No call synchronises the device except where stated: the *_create calls do
+ *    (once); vqcpc_vocoder_generate / _logits and vqcpc_melfront_run synchronise `stream`
+ *    while they upload host-built tables (lengths, decode-slot schedule) BEFORE enqueuing
+ *    their kernels, and return with the work still in flight; vqcpc_vocoder_kernel_times
+ *    is a measurement call and returns after its launches have finished.
  *  - Return 0 on success, a negative vqcpc_status otherwise; never throws.
  *    vqcpc_last_error() returns a thread-local message for the last failure.
  *  - One handle per device; a handle is not thread-safe; distinct handles are independent.
