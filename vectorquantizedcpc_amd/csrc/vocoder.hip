@@ -959,10 +959,11 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     }
     VQ_REQUIRE(total < (1L << 30), "vocoder: schedule too long");
     const int max_t = (int)total;
-    // Tile groups: 3..big_min_tiles-1 tiles split in two.  (Measured: 2 x 16 utterances is slower than one
+    // Tile groups: 3..big_min_tiles-1 tiles, or >= 2*big_min_tiles (both halves on the large-batch kernel), split in two.  (Measured: 2 x 16 utterances is slower than one
     // group of 32 -- the chip retires only ~0.43 dependent launches per us across queues -- while
     // 2 x 32 runs at 14.5 us per sample against 17.3 us for one group of 64.)
-    const bool split = v->two_groups && v->use_graph && nbt >= 3 && !(v->big_min_tiles > 0 && nbt >= v->big_min_tiles);
+    const bool split = v->two_groups && v->use_graph && nbt >= 3 &&
+                       !(v->big_min_tiles > 0 && nbt >= v->big_min_tiles && nbt < 2 * v->big_min_tiles);
     const int n_grp = split ? 2 : 1;
     const int tiles[2] = {split ? (nbt + 1) / 2 : nbt, split ? nbt / 2 : 0};
     const int slot0[2] = {0, tiles[0] * 16};
