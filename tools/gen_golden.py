@@ -11,8 +11,9 @@ of the bit patterns of each stage, a few full rows, float64 checksums.  Nothing 
 reference's source travels; the GPU box rebuilds inputs and weights from the seed.
 
 Vocoder half: the reference's arithmetic (third-party ``rnnms``) is absent, so there is
-nothing to import; ``vocoder_selforacle.npz`` is produced by this project's own CPU
-oracle and is labelled self-oracle (parity unpinned).
+nothing to import; ``vocoder_selforacle.npz`` / ``vocoder_glue.npz`` are produced by this
+project's own CPU oracle (``tests/golden/make_vocoder_fixtures.py``) and are labelled
+self-oracle (parity unpinned).
 
 Usage:  python tools/gen_golden.py            (writes tests/golden/)
 """
@@ -102,39 +103,6 @@ def encoder_fixture(model, name, B, T, ln_affine, codebook):
           f"loss={out['loss']:.6g} ppl={out['perplexity']:.6g}")
 
 
-def glue_fixture():
-    """network_vocoder.py:69-77 glue layout, restated with torch ops on CPU and frozen as data.
-
-    (The reference module itself needs ``rnnms`` to import; SURVEY 8c verified this layout
-    against the reference with a capture stub.  Parity of the recurrence stays unpinned.)
-    """
-    sd = synth.vocoder_state_dict()
-    z = synth.randint("glue/z", (2, 5), 512)
-    spk = synth.randint("glue/spk", (2,), 102)
-    ze = torch.nn.functional.embedding(z, sd["code_embedding.weight"])
-    zu = torch.nn.functional.interpolate(ze.transpose(1, 2), scale_factor=2).transpose(1, 2)
-    se = torch.nn.functional.embedding(spk, sd["speaker_embedding.weight"])
-    series = torch.cat((zu, se.unsqueeze(1).expand(-1, zu.size(1), -1)), dim=-1)
-    np.savez_compressed(os.path.join(GOLD, "vocoder_glue.npz"), z=z.numpy(), speaker=spk.numpy(),
-                        series=series.numpy())
-
-
-def vocoder_selforacle():
-    import oracle
-    sd = synth.vocoder_state_dict()
-    out = {}
-    for u, (tc, steps) in enumerate(((3, 960), (2, 640))):
-        z = synth.randint(f"voc/z{u}", (tc,), 512).numpy()
-        spk = int(synth.randint(f"voc/spk{u}", (1,), 102)[0])
-        r = oracle.vocoder_generate(sd, z, spk, seed=synth.SEED, utterance=u, n_steps=steps, want_logits=True)
-        out[f"z{u}"], out[f"spk{u}"] = z, np.array(spk)
-        out[f"samples{u}"] = r["samples"].astype(np.int16)
-        out[f"wav{u}"] = r["wav"]
-        out[f"logits{u}"] = r["logits"][::64].copy()       # every 64th step
-        out[f"cond{u}"] = oracle.vocoder_condition(sd, z, spk)
-    np.savez_compressed(os.path.join(GOLD, "vocoder_selforacle.npz"), **out)
-
-
 def main():
     os.makedirs(GOLD, exist_ok=True)
     model = import_reference()
@@ -142,8 +110,6 @@ def main():
           "| cpu capability", torch.backends.cpu.get_cpu_capability(), "| threads", torch.get_num_threads())
     for name, args in ENCODER_CASES.items():
         encoder_fixture(model, name, *args)
-    glue_fixture()
-    vocoder_selforacle()
     print("wrote", sorted(os.listdir(GOLD)))
 
 
