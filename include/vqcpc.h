@@ -14,7 +14,7 @@
  *    before the call returns.
  *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream).  No call synchronises the device except where stated: the *_create calls do
- *    (once); vqcpc_vocoder_generate / _logits and vqcpc_melfront_run synchronise `stream`
+ *    (once); vqcpc_vocoder_generate / _logits, vqcpc_melfront_run and vqcpc_loudness_* synchronise `stream`
  *    while they upload host-built tables (lengths, decode-slot schedule) BEFORE enqueuing
  *    their kernels, and return with the work still in flight; vqcpc_vocoder_kernel_times
  *    is a measurement call and returns after its launches have finished.
@@ -204,6 +204,27 @@ int vqcpc_melfront_frames(const vqcpc_melfront *f, int n_samples);
  * the encoder's input layout; frames past an utterance's own length are zero. */
 int vqcpc_melfront_run(vqcpc_melfront *f, const float *wav, const int *lens, int B, int Lmax, float *mel,
                        void *stream);
+
+/* ------------------------------------------------------------------ Loudness ---- */
+
+/* Replaces pyloudnorm.Meter(sr) (convert.py:50) for mono audio: ITU-R BS.1770-4 gated integrated
+ * loudness as pyloudnorm ^0.1.0 computes it (K-weighting biquads derived at `rate`, 400 ms blocks with
+ * 75 % overlap, gates at -70 LUFS absolute and -10 LU relative).  fp64 on the device. */
+typedef struct vqcpc_loudness vqcpc_loudness;
+int vqcpc_loudness_create(int rate, vqcpc_loudness **out);
+void vqcpc_loudness_destroy(vqcpc_loudness *m);
+/* Gating blocks of an n_samples signal; 0 when it is shorter than one block (the meter refuses it). */
+int vqcpc_loudness_blocks(const vqcpc_loudness *m, int n_samples);
+/* meter.integrated_loudness (convert.py:57, :79) of B padded mono signals.  wav DEVICE (B, Lmax) fp32,
+ * lens HOST (B); lufs DEVICE (B) fp64 (-inf when every block is gated out); block_energy DEVICE
+ * (sum of vqcpc_loudness_blocks(lens[b])) fp64 or NULL.  VQCPC_ERR_INVALID when an utterance is shorter
+ * than one block (pyloudnorm raises ValueError).  Synchronises `stream` once (host length tables). */
+int vqcpc_loudness_integrated(vqcpc_loudness *m, const float *wav, const int *lens, int B, int Lmax, double *lufs,
+                              double *block_energy, void *stream);
+/* pyloudnorm.normalize.loudness (convert.py:80), in place: wav[b] *= 10^((target[b] - measured[b]) / 20),
+ * product in fp64 rounded to fp32.  measured / target DEVICE (B) fp64. */
+int vqcpc_loudness_normalize(vqcpc_loudness *m, float *wav, const int *lens, int B, int Lmax, const double *measured,
+                             const double *target, void *stream);
 
 /* Average wall time, in microseconds, of `reps` back-to-back launches of each per-sample kernel
  * of the decode loop on the state the last generate()/logits() call left (HIP events on

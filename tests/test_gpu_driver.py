@@ -83,10 +83,13 @@ def test_cli_encode_and_convert_end_to_end(tmp_path):
                         seed=5, utt_ids=[0])
     assert sr == 16000 and np.array_equal(w, want[0].cpu().numpy())
     # wav input: the mel front-end runs on the GPU (convert.py:54-70)
-    tone = (0.2 * np.sin(2 * np.pi * 300 * np.arange(4800) / 16000)).astype(np.float32)
+    tone = (0.2 * np.sin(2 * np.pi * 300 * np.arange(8000) / 16000)).astype(np.float32)
     wavfile.write(str(ds / "test" / "W1.wav"), 16000, tone)
     (tmp_path / "list2.json").write_text(json.dumps([["test/W1", "V001", "o3"]]))
     assert cli.main(["convert", "--dataset", str(ds), "--synthesis-list", str(tmp_path / "list2.json"), "--in-dir", str(ds),
                      "--out-dir", str(tmp_path / "wav"), "--random-init"]) == 0
     sr, w3 = wavfile.read(tmp_path / "wav" / "o3.wav")
-    assert w3.shape == (320 * driver.out_frames(1 + 4800 // 160),)
+    assert w3.shape == (320 * driver.out_frames(1 + 8000 // 160),)
+    # convert.py:57,79-80: the output is re-normalised to the input's integrated loudness
+    from oracle import loudness_ref
+    assert abs(loudness_ref.integrated_loudness(w3, 16000) - loudness_ref.integrated_loudness(tone, 16000)) < 1e-4

@@ -18,6 +18,8 @@ SYMBOLS = [
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
     "vqcpc_melfront_create", "vqcpc_melfront_destroy", "vqcpc_melfront_frames", "vqcpc_melfront_run",
+    "vqcpc_loudness_create", "vqcpc_loudness_destroy", "vqcpc_loudness_blocks", "vqcpc_loudness_integrated",
+    "vqcpc_loudness_normalize",
 ]
 
 
@@ -81,6 +83,12 @@ def load():
     lib.vqcpc_melfront_destroy.restype = None
     lib.vqcpc_melfront_frames.argtypes = [vp, i32]
     lib.vqcpc_melfront_run.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, vp]
+    lib.vqcpc_loudness_create.argtypes = [i32, C.POINTER(vp)]
+    lib.vqcpc_loudness_destroy.argtypes = [vp]
+    lib.vqcpc_loudness_destroy.restype = None
+    lib.vqcpc_loudness_blocks.argtypes = [vp, i32]
+    lib.vqcpc_loudness_integrated.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, vp, vp]
+    lib.vqcpc_loudness_normalize.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, vp, vp]
     _lib = lib
     return lib
 

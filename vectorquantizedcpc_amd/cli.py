@@ -8,8 +8,9 @@
 
 ``encode`` mirrors ``encode.py:14-67``.  ``convert`` mirrors ``convert.py:17-83`` from the mel onwards: inputs are
 ``<in_dir>/<utterance>.mel.npy`` or, if absent, ``<utterance>.wav`` (16 kHz) run through the HIP mel
-front-end (``preprocess.wave_to_mel`` = ``convert.py:54-70``); the loudness re-normalisation of
-``convert.py:79-80`` (pyloudnorm, CPU) is not reproduced.  Utterances are batched by the
+front-end (``preprocess.wave_to_mel`` = ``convert.py:54-70``).  For ``.wav`` inputs the output is re-normalised
+to the input's integrated loudness (``convert.py:57,79-80``) by the HIP meter in ``loudness.py``; a ``.mel.npy``
+input carries no reference loudness and its output is written as generated.  Utterances are batched by the
 length-bucketed drivers; every output equals the batch-1 result.
 """
 import argparse
@@ -18,7 +19,7 @@ from pathlib import Path
 
 import torch
 
-from . import ConfEncoder, ConfVocoder, Encoder, Vocoder, driver, io, preprocess, synth
+from . import ConfEncoder, ConfVocoder, Encoder, Vocoder, driver, io, loudness, preprocess, synth
 
 
 def _models(args, need_vocoder):
@@ -64,13 +65,20 @@ def convert_dataset(args) -> int:
     in_dir, out_dir = Path(args.in_dir), Path(args.out_dir)
     out_dir.mkdir(exist_ok=True, parents=True)
     enc, voc = _models(args, need_vocoder=True)
-    mels = []
-    for p, _, _ in items:
+    mels, ref = [], {}
+    meter = loudness.Meter(16000)                              # convert.py:50
+    for i, (p, _, _) in enumerate(items):
         if (in_dir / p).with_suffix(".mel.npy").exists():
             mels.append(io.load_mel(in_dir / p))
         else:                                                  # convert.py:54-70: wav -> log-mel, on the GPU
-            mels.append(preprocess.wave_to_mel(io.load_wav(in_dir / p).to(args.device)))
+            wav = io.load_wav(in_dir / p).to(args.device)
+            ref[i] = meter.integrated_loudness(wav)            # convert.py:57 (before the peak normalisation)
+            mels.append(preprocess.wave_to_mel(wav))
     wavs = driver.convert_utterances(enc, voc, mels, [s for _, s, _ in items], seed=args.seed, max_batch=args.max_batch)
+    if ref:                                                    # convert.py:79-80, one batched call each way
+        ids = sorted(ref)
+        for i, w in zip(ids, loudness.match_loudness([wavs[i] for i in ids], [ref[i] for i in ids])):
+            wavs[i] = w
     for (_, _, name), w in zip(items, wavs):
         io.save_wav(out_dir / name, w, 16000)
     print(f"converted {len(items)} utterances -> {out_dir}")
