@@ -70,8 +70,6 @@ struct GemmP {
     int M, N, K, KC;
     // im2col source (AMODE 1/2): mel (B, C, T)
     const float *x; int C, T, To;
-    // VQ epilogue (EPI 1)
-    const float *e2, *x2; float *pd; int *pi; int npart;
 };
 
 template <int AMODE>
@@ -113,90 +111,121 @@ __device__ __forceinline__ void stage(float (*T)[GT_LD], int tid, const float (&
     for (int i = 0; i < 8; ++i) T[kq + i][row] = v[i];
 }
 
-template <int AMODE, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, const f32x16 &tot, int m0, int wm, int half, int col) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) p.Y[(size_t)m * p.ldy + col] = tot[r];
+    }
+}
+
+// Software pipeline.  A loop that does, per k tile, {wait for global loads, 16 LDS stores, barrier, 32 LDS
+// operand reads} and then its 16 MFMAs pays for both halves: measured on MI355X, 17 us of MFMA + 16 us of
+// LDS work for a 4096 x 512 x 512 layer that ran 28.6 us (tools/microbench_mfma.hip).  Here the
+// LDS tiles are double-buffered and every MFMA gap carries its share of the other work, in program order
+// (pinned with sched_barrier): MFMAs 0-7 of tile k are interleaved with the LDS stores of tile k+1, then the
+// global loads of tile k+2 are requested, one barrier, and MFMAs 8-15 are interleaved with the operand
+// reads of tile k+1 into a second register set.  22.5 us for the same layer, same k order, same bits.
+template <int AMODE, int C>
+__device__ __forceinline__ void pipe_body(const GemmP &p, float (*As)[GT_BK][GT_LD], float (*Ws)[GT_BK][GT_LD], int tid,
+                                          int m0, int n0, int k2, float (&va)[8], float (&vw)[8], float (&oa)[2][16],
+                                          float (&ob)[2][16], f32x16 &acc, int acol, int bcol, int half) {
+    const int row = tid >> 2, kq = (tid & 3) * 8;
+    float (*An)[GT_LD] = As[C ^ 1];
+    float (*Wn)[GT_LD] = Ws[C ^ 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[C][j], ob[C][j], acc, 0, 0, 0);
+        An[kq + j][row] = va[j];
+        Wn[kq + j][row] = vw[j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    fetch_a<AMODE>(p, m0, k2, tid, va);
+    fetch_w(p, n0, k2, tid, vw);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[C][8 + j], ob[C][8 + j], acc, 0, 0, 0);
+        oa[C ^ 1][2 * j] = An[4 * j + half][acol];
+        oa[C ^ 1][2 * j + 1] = An[4 * j + 2 + half][acol];
+        ob[C ^ 1][2 * j] = Wn[4 * j + half][bcol];
+        ob[C ^ 1][2 * j + 1] = Wn[4 * j + 2 + half][bcol];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void fold_chain(const GemmP &p, f32x16 &acc, f32x16 &tot, bool &first, float bv) {
+    if (first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[r] = p.bias ? bv + acc[r] : acc[r];
+        first = false;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[r] = tot[r] + acc[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+}
+
+template <int AMODE>
 __global__ __launch_bounds__(256) void gemm_chain_kernel(GemmP p) {
-    __shared__ float As[GT_BK][GT_LD];
-    __shared__ float Ws[GT_BK][GT_LD];
+    __shared__ float As[2][GT_BK][GT_LD];
+    __shared__ float Ws[2][GT_BK][GT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, li = lane & 31;
     const int n0 = blockIdx.x * GT_BN, m0 = blockIdx.y * GT_BM;
-    const int col = n0 + wn * 32 + li;
+    const int col = n0 + wn * 32 + li, acol = wm * 32 + li, bcol = wn * 32 + li;
+    const int nt = p.K / GT_BK, tpb = p.KC / GT_BK;
 
     f32x16 acc, tot;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; tot[r] = 0.f; }
     bool first = true;
+    const float bv = p.bias ? p.bias[col] : 0.f;
 
-    // register prefetch: the next k tile's global loads fly underneath this tile's MFMAs
-    float va[8], vw[8];
+    float va[8], vw[8], oa[2][16], ob[2][16];
     fetch_a<AMODE>(p, m0, 0, tid, va);
     fetch_w(p, n0, 0, tid, vw);
-    for (int k0 = 0; k0 < p.K; k0 += GT_BK) {
-        __syncthreads();
-        stage(As, tid, va);
-        stage(Ws, tid, vw);
-        __syncthreads();
-        if (k0 + GT_BK < p.K) {
-            fetch_a<AMODE>(p, m0, k0 + GT_BK, tid, va);
-            fetch_w(p, n0, k0 + GT_BK, tid, vw);
-        }
+    stage(As[0], tid, va);
+    stage(Ws[0], tid, vw);
+    const int k1 = nt > 1 ? GT_BK : 0;
+    fetch_a<AMODE>(p, m0, k1, tid, va);
+    fetch_w(p, n0, k1, tid, vw);
+    __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < GT_BK / 2; ++kk) {
-            const float a = As[2 * kk + half][wm * 32 + li];
-            const float b = Ws[2 * kk + half][wn * 32 + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        if ((k0 + GT_BK) % p.KC == 0 || k0 + GT_BK >= p.K) {       // end of a K block: fold the chain
-            if (first) {
-                const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[r] = p.bias ? bv + acc[r] : acc[r];
-                first = false;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[r] = tot[r] + acc[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
+    for (int kk = 0; kk < 16; ++kk) {
+        oa[0][kk] = As[0][2 * kk + half][acol];
+        ob[0][kk] = Ws[0][2 * kk + half][bcol];
     }
 
-    if (EPI == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < p.M) p.Y[(size_t)m * p.ldy + col] = tot[r];
-        }
-    } else {
-        // VQ distance + per-32-code partial argmin (model.py:107-112).
-        const float e2 = p.e2[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float x2 = p.x2[m < p.M ? m : p.M - 1];
-            float d = __builtin_fmaf(-2.0f, tot[r], e2 + x2);
-            int j = col;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                const float od = __shfl_xor(d, off);
-                const int oj = __shfl_xor(j, off);
-                if (od < d || (od == d && oj < j)) { d = od; j = oj; }
-            }
-            if (li == 0 && m < p.M) {
-                const int part = blockIdx.x * 2 + wn;
-                p.pd[(size_t)m * p.npart + part] = d;
-                p.pi[(size_t)m * p.npart + part] = j;
-            }
-        }
+    int k = 0;
+    for (; k + 2 < nt; k += 2) {
+        pipe_body<AMODE, 0>(p, As, Ws, tid, m0, n0, (k + 2) * GT_BK, va, vw, oa, ob, acc, acol, bcol, half);
+        if ((k + 1) % tpb == 0) fold_chain(p, acc, tot, first, bv);
+        pipe_body<AMODE, 1>(p, As, Ws, tid, m0, n0, (k + 3 < nt ? k + 3 : nt - 1) * GT_BK, va, vw, oa, ob, acc, acol, bcol, half);
+        if ((k + 2) % tpb == 0) fold_chain(p, acc, tot, first, bv);
     }
+    if (k + 1 < nt) {                                                 // two tiles left
+        pipe_body<AMODE, 0>(p, As, Ws, tid, m0, n0, (nt - 1) * GT_BK, va, vw, oa, ob, acc, acol, bcol, half);
+        if ((k + 1) % tpb == 0) fold_chain(p, acc, tot, first, bv);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[1][kk], ob[1][kk], acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[0][kk], ob[0][kk], acc, 0, 0, 0);
+    }
+    fold_chain(p, acc, tot, first, bv);
+
+    gemm_epilogue(p, tot, m0, wm, half, col);
 }
 
-template <int AMODE, int EPI>
+template <int AMODE>
 static int launch_gemm(const GemmP &p, hipStream_t s) {
     VQ_REQUIRE(p.N % GT_BN == 0 && p.K % GT_BK == 0 && p.KC % GT_BK == 0 && p.M > 0,
                "gemm_chain: unsupported shape M=%d N=%d K=%d KC=%d", p.M, p.N, p.K, p.KC);
     dim3 grid(p.N / GT_BN, (p.M + GT_BM - 1) / GT_BM);
-    hipLaunchKernelGGL((gemm_chain_kernel<AMODE, EPI>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_chain_kernel<AMODE>), grid, dim3(256), 0, s, p);
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
 }
@@ -208,7 +237,7 @@ int vq_gemm_chain(const float *A, int lda, const float *W, const float *bias, fl
     GemmP p{};
     p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.Y = Y; p.ldy = ldy;
     p.M = M; p.N = N; p.K = K; p.KC = KC;
-    return launch_gemm<0, 0>(p, s);
+    return launch_gemm<0>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,20 +339,121 @@ __global__ void rowsumsq64_kernel(const float *__restrict__ X, float *__restrict
     if (i < n) out[i] = sumsq64(X + (size_t)i * 64);
 }
 
-// First-index argmin over the per-32-code partials + F.embedding gather (model.py:112-115).
-__global__ void vq_finalize_kernel(const float *__restrict__ pd, const int *__restrict__ pi, int npart,
-                                   const float *__restrict__ E, int64_t *__restrict__ idx,
-                                   float *__restrict__ zq, int n) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n) return;
-    float best = pd[(size_t)row * npart];
-    int bj = pi[(size_t)row * npart];
-    for (int q = 1; q < npart; ++q) {
-        const float d = pd[(size_t)row * npart + q];
-        if (d < best) { best = d; bj = pi[(size_t)row * npart + q]; }
+// ------------------------------------------------------------------------------------------
+// VQEmbeddingEMA.encode (model.py:103-115) in one kernel: |x|^2, the distance matrix row block,
+// first-index argmin and the F.embedding gather.  One 256-thread workgroup per 16 rows; each wave owns a
+// quarter of the codes and runs them as 16x16 tiles on v_mfma_f32_16x16x4_f32 with ONE accumulator per
+// tile, so a dot product is the k-ascending fmaf chain of the reference's addmm (K = 64 is a single MKL
+// block); two tiles are interleaved to cover the MFMA's dependent latency.
+// Codebook fragments: Ef[(t*4 + q)*64 + lane] (float4) = E[16t + (lane&15)][16q + 4c + (lane>>4)], c = .x.y.z.w
+// ------------------------------------------------------------------------------------------
+__global__ void vq_build_frag_kernel(const float *__restrict__ E, float4 *__restrict__ Ef, int n_emb) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_emb * 16) return;
+    const int lane = id & 63, q = (id >> 6) & 3, t = id >> 8;
+    const float *r = E + (size_t)(16 * t + (lane & 15)) * 64 + 16 * q + (lane >> 4);
+    Ef[id] = make_float4(r[0], r[4], r[8], r[12]);
+}
+
+__device__ __forceinline__ void vq_load_tile(const float4 *__restrict__ Ef, int t, int lane, float4 (&f)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = Ef[(size_t)(t * 4 + q) * 64 + lane];
+}
+__device__ __forceinline__ void vq_take(const f32x4 &acc, int code, float e2, const float (&x2)[4], float (&bd)[4], int (&bj)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float d = __builtin_fmaf(-2.0f, acc[r], e2 + x2[r]);
+        if (d < bd[r]) { bd[r] = d; bj[r] = code; }
     }
-    if (lane == 0) idx[row] = bj;
-    zq[(size_t)row * 64 + lane] = E[(size_t)bj * 64 + lane];
+}
+
+__global__ __launch_bounds__(256) void vq_encode_kernel(const float *__restrict__ X, int N, const float4 *__restrict__ Ef,
+                                                        const float *__restrict__ E, const float *__restrict__ e2, int n_emb,
+                                                        int64_t *__restrict__ idx, float *__restrict__ zq) {
+    __shared__ float xs[16][68];
+    __shared__ float x2s[16];
+    __shared__ float cd[4][16];
+    __shared__ int cj[4][16];
+    __shared__ int best[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
+    {
+        const int row = tid >> 4, c4 = tid & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < N) v = ((const float4 *)X)[(size_t)(r0 + row) * 16 + c4];
+        xs[row][4 * c4 + 0] = v.x; xs[row][4 * c4 + 1] = v.y; xs[row][4 * c4 + 2] = v.z; xs[row][4 * c4 + 3] = v.w;
+    }
+    if (tid < 16) x2s[tid] = r0 + tid < N ? sumsq64(X + (size_t)(r0 + tid) * 64) : 0.f;
+    const int tpw = n_emb / 64, t0 = wave * tpw;                       // 16-code tiles per wave, this wave's first
+    float4 f0[4], f1[4];
+    vq_load_tile(Ef, t0, lane, f0);
+    if (tpw > 1) vq_load_tile(Ef, t0 + 1, lane, f1);
+    __syncthreads();
+    float a[16], x2[4], bd[4];
+    int bj[4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = xs[lane & 15][4 * j + (lane >> 4)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x2[r] = x2s[4 * (lane >> 4) + r]; bd[r] = __builtin_inff(); bj[r] = 0; }
+
+    int tt = 0;
+    for (; tt + 1 < tpw; tt += 2) {
+        const int t = t0 + tt, c0 = 16 * t + (lane & 15);
+        const float ea = e2[c0], eb = e2[c0 + 16];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 0], f0[q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 0], f1[q].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 1], f0[q].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 1], f1[q].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 2], f0[q].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 2], f1[q].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 3], f0[q].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 3], f1[q].w, acc1, 0, 0, 0);
+        }
+        if (tt + 2 < tpw) vq_load_tile(Ef, t + 2, lane, f0);           // next pair streams in under the compares
+        if (tt + 3 < tpw) vq_load_tile(Ef, t + 3, lane, f1);
+        vq_take(acc0, c0, ea, x2, bd, bj);
+        vq_take(acc1, c0 + 16, eb, x2, bd, bj);
+    }
+    if (tt < tpw) {                                                    // odd tile count: last tile alone
+        const int c0 = 16 * (t0 + tt) + (lane & 15);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 0], f0[q].x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 1], f0[q].y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 2], f0[q].z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 3], f0[q].w, acc0, 0, 0, 0);
+        }
+        vq_take(acc0, c0, e2[c0], x2, bd, bj);
+    }
+    // first-index argmin: over the 16 codes of a lane group, then over the four waves (ascending codes)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const float od = __shfl_xor(bd[r], off);
+            const int oj = __shfl_xor(bj[r], off);
+            if (od < bd[r] || (od == bd[r] && oj < bj[r])) { bd[r] = od; bj[r] = oj; }
+        }
+        if ((lane & 15) == 0) { cd[wave][4 * (lane >> 4) + r] = bd[r]; cj[wave][4 * (lane >> 4) + r] = bj[r]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float d = cd[0][tid];
+        int j = cj[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (cd[w][tid] < d) { d = cd[w][tid]; j = cj[w][tid]; }
+        best[tid] = j;
+        if (r0 + tid < N) idx[r0 + tid] = j;
+    }
+    __syncthreads();
+    {
+        const int row = tid >> 4, c4 = tid & 15;                       // F.embedding gather (model.py:113)
+        if (r0 + row < N) ((float4 *)zq)[(size_t)(r0 + row) * 16 + c4] = ((const float4 *)E)[(size_t)best[row] * 16 + c4];
+    }
 }
 
 // Eval-branch statistics of VQEmbeddingEMA.forward (model.py:147-153): deterministic two-level
@@ -394,10 +524,10 @@ struct vqcpc_encoder {
     float *ln_g[5] = {}, *ln_b[5] = {};
     float *fc_w[4] = {};
     float *out_w = nullptr, *out_b = nullptr;
-    float *codebook = nullptr, *e2 = nullptr;
+    float *codebook = nullptr, *e2 = nullptr, *cbfrag = nullptr;
     LstmPlan *lstm = nullptr;
     LnConst lnc;
-    DevBuf bufA, bufB, x2, pd, pi, zpre, stats;
+    DevBuf bufA, bufB, zpre, stats;
 };
 
 static int dev_copy(float **dst, const float *src, size_t n) {
@@ -409,12 +539,12 @@ static int dev_copy(float **dst, const float *src, size_t n) {
 
 extern "C" void vqcpc_encoder_destroy(vqcpc_encoder *e) {
     if (!e) return;
-    float *ptrs[] = {e->conv_w1, e->conv_w2, e->out_w, e->out_b, e->codebook, e->e2};
+    float *ptrs[] = {e->conv_w1, e->conv_w2, e->out_w, e->out_b, e->codebook, e->e2, e->cbfrag};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) { if (e->ln_g[i]) (void)hipFree(e->ln_g[i]); if (e->ln_b[i]) (void)hipFree(e->ln_b[i]); }
     for (int i = 0; i < 4; ++i) if (e->fc_w[i]) (void)hipFree(e->fc_w[i]);
     if (e->lstm) vq_lstm_plan_destroy(e->lstm);
-    e->bufA.release(); e->bufB.release(); e->x2.release(); e->pd.release(); e->pi.release();
+    e->bufA.release(); e->bufB.release();
     e->zpre.release(); e->stats.release();
     delete e;
 }
@@ -438,6 +568,9 @@ static int encoder_create_impl(const vqcpc_encoder_weights *w, vqcpc_encoder *e)
     HIP_TRY(hipMalloc((void **)&e->e2, w->n_embeddings * sizeof(float)));
     hipLaunchKernelGGL(rowsumsq64_kernel, dim3((w->n_embeddings + 63) / 64), dim3(64), 0, 0, e->codebook, e->e2,
                        w->n_embeddings);
+    HIP_TRY(hipMalloc((void **)&e->cbfrag, (size_t)w->n_embeddings * 64 * sizeof(float)));
+    hipLaunchKernelGGL(vq_build_frag_kernel, dim3((w->n_embeddings * 16 + 255) / 256), dim3(256), 0, 0, e->codebook,
+                       (float4 *)e->cbfrag, w->n_embeddings);
     HIP_TRY(hipGetLastError());
     TRY(vq_lstm_plan_create(w->rnn_w_ih, w->rnn_w_hh, w->rnn_b_ih, w->rnn_b_hh, w->z_dim, w->c_dim, &e->lstm));
     HIP_TRY(hipDeviceSynchronize());
@@ -479,8 +612,8 @@ static int encoder_front(vqcpc_encoder *e, const float *mel, int B, int T, int c
     p.Y = a; p.ldy = CH; p.M = N; p.N = CH; p.K = 4 * C;
     p.KC = conv_mode == VQCPC_CONV_IM2COL ? 4 * C : 64;
     p.x = mel; p.C = C; p.T = T; p.To = To;
-    if (conv_mode == VQCPC_CONV_IM2COL) TRY((launch_gemm<1, 0>(p, s)));
-    else TRY((launch_gemm<2, 0>(p, s)));
+    if (conv_mode == VQCPC_CONV_IM2COL) TRY((launch_gemm<1>(p, s)));
+    else TRY((launch_gemm<2>(p, s)));
     *stage_out = a;
     if (stop_stage == 0) return VQCPC_OK;
 
@@ -510,10 +643,6 @@ extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, i
     VQ_REQUIRE(conv_mode >= 0 && conv_mode <= 2, "encoder.encode: conv_mode must be 0, 1 or 2");
     hipStream_t s = (hipStream_t)stream;
     const int To = (T - 2) / 2 + 1, N = B * To;
-    TRY(e->x2.reserve((size_t)N * sizeof(float)));
-    const int npart = e->n_emb / 32;
-    TRY(e->pd.reserve((size_t)N * npart * sizeof(float)));
-    TRY(e->pi.reserve((size_t)N * npart * sizeof(int)));
     float *zp = z_pre;
     if (!zp) { TRY(e->zpre.reserve((size_t)N * 64 * sizeof(float))); zp = e->zpre.as<float>(); }
     VQ_REQUIRE(((uintptr_t)zp & 15) == 0 && ((uintptr_t)z_q & 15) == 0, "encoder.encode: outputs must be 16-byte aligned");
@@ -521,13 +650,8 @@ extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, i
     TRY(encoder_front(e, mel, B, T, conv_mode, 10, zp, &unused, s));
 
     // VQ (model.py:103-115)
-    hipLaunchKernelGGL(rowsumsq64_kernel, dim3((N + 63) / 64), dim3(64), 0, s, zp, e->x2.as<float>(), N);
-    GemmP q{};
-    q.A = zp; q.lda = 64; q.W = e->codebook; q.M = N; q.N = e->n_emb; q.K = 64; q.KC = 64;
-    q.e2 = e->e2; q.x2 = e->x2.as<float>(); q.pd = e->pd.as<float>(); q.pi = e->pi.as<int>(); q.npart = npart;
-    TRY((launch_gemm<0, 1>(q, s)));
-    hipLaunchKernelGGL(vq_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, e->pd.as<float>(), e->pi.as<int>(),
-                       npart, e->codebook, idx, z_q, N);
+    hipLaunchKernelGGL(vq_encode_kernel, dim3((N + 15) / 16), dim3(256), 0, s, zp, N, (const float4 *)e->cbfrag, e->codebook,
+                       e->e2, e->n_emb, idx, z_q);
     HIP_TRY(hipGetLastError());
     if (c) TRY(vq_lstm_run(e->lstm, z_q, B, To, c, s));
     return VQCPC_OK;
