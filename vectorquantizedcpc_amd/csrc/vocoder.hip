@@ -122,41 +122,54 @@ __global__ __launch_bounds__(256) void seq_step_kernel(SeqP p, int step) {
     const size_t hsz = (size_t)p.nbt * H * 16;
     const float *hin = p.hbuf + ((size_t)(step & 1) * p.ndir + dir) * hsz;
     float *hout = p.hbuf + ((size_t)((step + 1) & 1) * p.ndir + dir) * hsz;
-    float4 wf[SW];
-    load_wfrag<SW>(p.Wf + (size_t)dir * (H / 4) * (H / 16) * 64 * 4, rg, 4, wave, lane, wf);
-    {
-        const int bt = blockIdx.z;                 // one utterance tile per workgroup
-        const f32x4 acc = mv16<SW>(wf, hin, H, bt, wave, lane);
-        const float v = reduce4(red, acc, wave, lane, tid);
-        gate[tid >> 4][tid & 15] = v;
-        __syncthreads();
-        if (tid < 64) {
-            const int u = tid >> 4, b = tid & 15, bg = bt * 16 + b;
-            const int L = p.len ? p.len[bg] : (bg < p.B ? p.T : 0);
-            if (step < L) {
-                const int tpos = dir == 0 ? step : L - 1 - step;
-                const int unit = 4 * rg + u;
-                const float *gi = p.Gi + ((size_t)bg * p.T + tpos) * (p.ndir * G * H) + (size_t)dir * G * H + unit;
-                const size_t hi = hl_index(H, bg, unit);
-                float hn;
-                if (G == 3) {
-                    const float *bh = p.b_hh + (size_t)dir * 3 * H + unit;
-                    const float r = sigmoidf_(gi[0] + (gate[u][b] + bh[0]));
-                    const float z = sigmoidf_(gi[H] + (gate[4 + u][b] + bh[H]));
-                    const float n = tanhf(gi[2 * H] + r * (gate[8 + u][b] + bh[2 * H]));
-                    hn = (1.0f - z) * n + z * hin[hi];
-                } else {
-                    float *cs = p.cbuf + (size_t)dir * hsz + hi;
-                    const float ig = sigmoidf_(gi[0] + gate[u][b]), fg = sigmoidf_(gi[H] + gate[4 + u][b]);
-                    const float gg = tanhf(gi[2 * H] + gate[8 + u][b]), og = sigmoidf_(gi[3 * H] + gate[12 + u][b]);
-                    const float cn = fg * (*cs) + ig * gg;
-                    *cs = cn;
-                    hn = og * tanhf(cn);
-                }
-                hout[hi] = hn;
-                p.out[((size_t)bg * p.T + tpos) * (p.ndir * H) + (size_t)dir * H + unit] = hn;
+    const int bt = blockIdx.z;                     // one utterance tile per workgroup
+    // cell-update operands of wave 0's lanes are requested first: they do not depend on this step's
+    // W_hh h, so their latency hides under the fragment loads and the MFMAs
+    const int u = (tid >> 4) & 3, b = tid & 15, bg = bt * 16 + b, unit = 4 * rg + u;
+    bool act = false;
+    int tpos = 0;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f, cold = 0.f;
+    const size_t hi = hl_index(H, bg, unit);
+    if (tid < 64) {
+        const int L = p.len ? p.len[bg] : (bg < p.B ? p.T : 0);
+        if (step < L) {
+            act = true;
+            tpos = dir == 0 ? step : L - 1 - step;
+            const float *gi = p.Gi + ((size_t)bg * p.T + tpos) * (p.ndir * G * H) + (size_t)dir * G * H + unit;
+            g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H];
+            if (G == 3) {
+                const float *bh = p.b_hh + (size_t)dir * 3 * H + unit;
+                bh0 = bh[0]; bh1 = bh[H]; bh2 = bh[2 * H];
+                hold = hin[hi];
+            } else {
+                g3 = gi[3 * H];
+                cold = p.cbuf[(size_t)dir * hsz + hi];
             }
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 wf[SW];
+    load_wfrag<SW>(p.Wf + (size_t)dir * (H / 4) * (H / 16) * 64 * 4, rg, 4, wave, lane, wf);
+    const f32x4 acc = mv16<SW>(wf, hin, H, bt, wave, lane);
+    const float v = reduce4(red, acc, wave, lane, tid);
+    gate[tid >> 4][tid & 15] = v;
+    __syncthreads();
+    if (act) {
+        float hn;
+        if (G == 3) {
+            const float r = sigmoidf_(g0 + (gate[u][b] + bh0));
+            const float z = sigmoidf_(g1 + (gate[4 + u][b] + bh1));
+            const float n = tanhf(g2 + r * (gate[8 + u][b] + bh2));
+            hn = (1.0f - z) * n + z * hold;
+        } else {
+            const float ig = sigmoidf_(g0 + gate[u][b]), fg = sigmoidf_(g1 + gate[4 + u][b]);
+            const float gg = tanhf(g2 + gate[8 + u][b]), og = sigmoidf_(g3 + gate[12 + u][b]);
+            const float cn = fg * cold + ig * gg;
+            p.cbuf[(size_t)dir * hsz + hi] = cn;
+            hn = og * tanhf(cn);
+        }
+        hout[hi] = hn;
+        p.out[((size_t)bg * p.T + tpos) * (p.ndir * H) + (size_t)dir * H + unit] = hn;
     }
 }
 
