@@ -110,6 +110,23 @@ def test_both_conv_backends_match_oracle():
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), mode
 
 
+@pytest.mark.parametrize("n_emb", [64, 192, 320, 1024])
+def test_other_codebook_sizes_match_oracle(n_emb):
+    """VQ kernel paths the 512-code fixtures do not reach: one 16-code tile per wave (64), odd tile counts
+    (192, 320), many tiles (1024); 21 rows (not a multiple of the kernel's 16-row block).  Checked bit-exact
+    against the pinned C oracle (a data-scale codebook, so the argmin is well separated from ties)."""
+    sd = synth.encoder_state_dict(n_embeddings=n_emb, ln_affine="random", codebook="data")
+    enc = V.Encoder(V.ConfEncoder(80, 512, n_emb, 64, 256))
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    mel = synth.mel("cb%d" % n_emb, 3, 14)                     # 3 x 7 = 21 rows
+    want = oracle.encoder_encode(sd, mel.numpy(), want_c=False, conv_mode=2)
+    z, _, idx = enc.encode(mel.cuda())
+    assert idx.shape == (3, 7) and int(idx.max()) < n_emb
+    assert np.array_equal(idx.cpu().numpy().ravel(), want["indices"].ravel())
+    assert np.array_equal(z.cpu().numpy().reshape(-1, 64).view(np.uint32), want["z"].reshape(-1, 64).view(np.uint32))
+
+
 def test_hook_and_error_surface():
     enc, _ = encoder_for("init", "init")
     seen = []
