@@ -260,18 +260,38 @@ struct ArCall {
     float *logits;             // (B, Ts, n_cls) or null
     const ArSlot *slots;       // [replays][Sp] what every decode slot is doing during each graph replay
     int S, Sp;                 // steps per replay (t_base is a multiple of it), slots (multiple of 16)
+    int n_rep;                 // rows of `slots`
     int F, Ts, Lout, max_t, nbt;
     unsigned long long seed;
     int t_base;                // advanced on device after every graph replay
 };
 
+// Timeline stamps of workgroup (0, 0) (100 MHz wall clock) for tools/decode_timeline.py: compiled in only
+// with -DVQCPC_AR_STAMPS (a debug build under build/stamps/, never the shipped library).
+#ifdef VQCPC_AR_STAMPS
+__device__ unsigned long long g_ar_stamps[160 * 3 * 6];
+#define AR_STAMP(cond, kern, i) do { if ((cond) && blockIdx.x == 1 && blockIdx.y == 0 && t_local < 160) \
+        g_ar_stamps[(t_local * 3 + (kern)) * 6 + (i)] = wall_clock64(); } while (0)
+extern "C" int vqcpc_debug_ar_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ar_stamps), sizeof(g_ar_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define AR_STAMP(cond, kern, i) do { } while (0)
+#endif
+
 struct ArModel {               // constant per handle (baked into the captured graph)
     const float *Wf_hh, *b_hh, *Gemb;
+    float *gcur;               // [Sp][3Hr] the Gcond row every slot uses during the replay in flight (gc_replay)
+    int gc_replay;             // 1: upsample % steps_per_graph == 0, so a slot stays on one conditioning frame per replay
+    int live_last;             // decode slots in use in the last tile (1..16): lanes of dead columns re-read column 0
+    int lead6;                 // ar_gru_kernel requests fragments 6 super-steps ahead instead of 3 (see there)
     const float *Wf_fc1, *b_fc1, *Wf_fc2, *b_fc2, *mulaw_tab;
     float *hbuf;               // [2][nbt][Hr*16]
     float *a1;                 // [nbt][Hf*16]
     float *cand_s;             // [Bpad][16] best score of each 16-class row group
     int *cand_k;               // [Bpad][16] its class
+    ArSlot *cur;               // [Sp] the slot row of the replay in flight (copied from ArCall::slots between
+                               // replays): a fixed address, so the step kernels read it without first waiting for ArCall
     int Hr, Hf, n_cls, upsample;
 };
 
@@ -298,9 +318,13 @@ __device__ __forceinline__ int merge_candidates16(const Cand16 &cd) {
     return k;
 }
 
+// `live` = columns (decode slots) of tile bt in use: a lane of a dead column re-reads column 0 of its k group
+// (same address as a live lane, so it costs no traffic) instead of streaming padding -- at one utterance
+// that is 15/16 of the state bytes.
 template <int SW>
-__device__ __forceinline__ void load_hfrag(const float *hL, int K, int bt, int wave, int lane, float4 (&hv)[SW]) {
-    const float4 *hp = (const float4 *)hL + ((size_t)bt * (K >> 2)) * 16 + (size_t)wave * SW * 64 + lane;
+__device__ __forceinline__ void load_hfrag(const float *hL, int K, int bt, int wave, int lane, int live, float4 (&hv)[SW]) {
+    const int hl = (lane & 15) < live ? lane : (lane & 48);
+    const float4 *hp = (const float4 *)hL + ((size_t)bt * (K >> 2)) * 16 + (size_t)wave * SW * 64 + hl;
 #pragma unroll
     for (int s = 0; s < SW; ++s) hv[s] = hp[s * 64];
 }
@@ -317,25 +341,29 @@ __device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 
     return a0 + a1;
 }
 
-// Scheduling notes (checked in the .s): hipcc otherwise sinks each fragment load down to its
-// MFMA (load 2, wait, 4 MFMA, ...), hoists the call-record load and the exit branch above
-// everything, and falls back to vmcnt(0) around divergent branches.  So: sched_barrier(0) pins
-// "all fragment loads first"; there is no early return (stores are predicated); the ping-pong
-// parity of the state buffers comes from the launch index (steps_per_graph is even, t_base a
-// multiple of it), so fragments are requested before the call record has arrived; and the GRU
-// kernel is WAVE-SPECIALISED: waves 0-3 run a branch-free load -> MFMA -> LDS stream over the
-// four K quarters, waves 4.. (one per utterance tile in flight) chase the dependent loads of the
-// cell update (candidates -> x -> Gemb row, Gcond, biases, old state) meanwhile.
-template <int SW, int NB>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
+// Scheduling notes (checked in the .s and with tools/decode_timeline.py): hipcc otherwise sinks each fragment
+// load down to its MFMA (load 2, wait, 4 MFMA, ...), hoists the call-record load and the exit branch above
+// everything, and falls back to vmcnt(0) around divergent branches.  So: sched_barrier(0) pins the request
+// order; there is no early return (stores are predicated); the ping-pong parity of the state buffers comes
+// from the launch index (steps_per_graph is even, t_base a multiple of it); and the GRU kernel is
+// WAVE-SPECIALISED: the first NB waves (one per utterance tile in flight) chase the dependent loads of the
+// cell update (candidates -> x -> Gemb row; slot record, Gcond row, biases and old state at fixed addresses),
+// the next four run a branch-free load -> MFMA -> LDS stream over the four K quarters.
+template <int SW, int NB, int LEADP>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
 __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
     __shared__ float red[NB][4][16][17];
+    __shared__ __attribute__((aligned(16))) float mt[256];            // mu-law decode table (row group 0 emits the samples)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, Hr = m.Hr;
     const size_t hsz = (size_t)nbt * Hr * 16;
     const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
     float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
-    const bool mfma_wave = wave < 4;                 // wave-uniform
-    const int g = wave - 4;                          // gate wave index = tile slot
+    // Waves 0..NB-1 chase the cell update's operands, waves NB..NB+3 run the MFMAs: the memory pipeline serves
+    // the oldest wave first, so the short dependent chain must live in the low wave slots (with the roles the
+    // other way round its requests arrived after the whole fragment stream: tools/decode_timeline.py).
+    const bool mfma_wave = wave >= NB;               // wave-uniform
+    const int g = wave, kw = wave - NB;              // gate wave index = tile slot; MFMA wave's K quarter
     const int u = lane >> 4, b = lane & 15, unit = 4 * rg + u;
+    AR_STAMP(tid == 64 * NB, 0, 0);
 
     // one pass of NB tiles per workgroup: grid.y = passes, so co-resident workgroups overlap one
     // pass's fragment loads with another's MFMAs when many utterances are in flight
@@ -344,40 +372,85 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
         bool active = false, first = false;
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
         size_t hi = 0;
+        int xraw = 0;
+        bool emit = false;
+        float *wavp = nullptr;
+        int64_t *mulp = nullptr;
         if (mfma_wave) {
-            // request order = consumption order (super-step s of the weights, then of every tile):
-            // the first MFMAs start while the tail of the fragments is still in flight
+            // Fragments are requested LEADP super-steps ahead of their MFMAs, not all at once.  Measured
+            // (bench.py, us per sample step): all 14 at once 12.76 at 32 utterances / 22.7 at 112; 6 ahead
+            // 12.17 / 23.2 and 14.5 at 64; 3 ahead 12.13 / 20.75 but 15.6 at 64 (two 2-tile groups on two
+            // streams want more in flight).  launch_ar_steps picks 6 for that case, 3 otherwise.
+            constexpr int LEAD = SW < LEADP ? SW : LEADP;
             float4 wf[SW], hv[NB][SW];
-            const float4 *wp = (const float4 *)m.Wf_hh + ((size_t)(rg * 4 + wave) * SW) * 64 + lane;
+            const float4 *wp = (const float4 *)m.Wf_hh + ((size_t)(rg * 4 + kw) * SW) * 64 + lane;
             const float4 *hp[NB];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int bt = bt0 + q < nbt ? bt0 + q : nbt - 1;        // clamped: no branch around loads
-                hp[q] = (const float4 *)hin + ((size_t)bt * (Hr >> 2)) * 16 + (size_t)wave * SW * 64 + lane;
+                const int live = bt == nbt - 1 ? m.live_last : 16;       // dead columns re-read column 0 (load_hfrag)
+                const int hl = (lane & 15) < live ? lane : (lane & 48);
+                hp[q] = (const float4 *)hin + ((size_t)bt * (Hr >> 2)) * 16 + (size_t)kw * SW * 64 + hl;
             }
 #pragma unroll
-            for (int s = 0; s < SW; ++s) {
+            for (int s = 0; s < LEAD; ++s) {
                 wf[s] = wp[s * 64];
 #pragma unroll
                 for (int q = 0; q < NB; ++q) hv[q][s] = hp[q][s * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
+            f32x4 a0[NB], a1[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) { a0[q] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                if (s + LEAD < SW) {
+                    wf[s + LEAD] = wp[(s + LEAD) * 64];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) hv[q][s + LEAD] = hp[q][(s + LEAD) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {                           // same chains as mfma_frag: (x, z) -> a0, (y, w) -> a1
+                    a0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv[q][s].x, a0[q], 0, 0, 0);
+                    a1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv[q][s].y, a1[q], 0, 0, 0);
+                    a0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv[q][s].z, a0[q], 0, 0, 0);
+                    a1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv[q][s].w, a1[q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                const f32x4 acc = mfma_frag<SW>(wf, hv[q]);
+                const f32x4 acc = a0[q] + a1[q];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[q][wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+                for (int r = 0; r < 4; ++r) red[q][kw][(lane >> 4) * 4 + r][lane & 15] = acc[r];
             }
+            AR_STAMP(tid == 64 * NB, 0, 1);
         } else {
             const int bt = bt0 + g;
             const int sg = (bt < nbt ? bt : nbt - 1) * 16 + b;           // decode slot
+            // The cell update's operands form a dependent chain (candidates -> x -> Gemb row).  Everything that
+            // has a fixed address is requested up front -- candidates, slot record, call record, biases, old
+            // state, the slot's Gcond row of this replay (gcur) -- so that only the Gemb row is a second level.
             Cand16 cd;
             load_candidates16(m, sg, cd);
+            const ArSlot sl = m.cur[sg];
             const ArCall c = *cp;
+            const float *bh = m.b_hh + unit;
+            bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
+            hi = hl_index(Hr, sg, unit);
+            const float hprev = hin[hi];
+            {                                                            // no branch around loads: gcur always exists
+                const float *gc = m.gcur + (size_t)sg * 3 * Hr + unit;
+                gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
+            }
+            float4 mtl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rg == 0 && wave == 0) mtl = ((const float4 *)m.mulaw_tab)[4 * lane < m.n_cls ? lane : 0];
+            __builtin_amdgcn_sched_barrier(0);
             const int t = c.t_base + t_local;
-            const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
             const int lt = t - sl.t0;                                    // sample index inside the utterance
             active = bt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
+            AR_STAMP(tid == 0 && (active || !active), 0, 4);
             first = lt == 0;
             if (active) {
                 int x;
@@ -385,24 +458,28 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
                 else if (first) x = m.n_cls / 2;
                 else {
                     x = merge_candidates16(cd);
-                    if (rg == 0 && u == 0) {                    // emit sample lt-1 (network_vocoder.py:78 output)
-                        if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
-                        if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
-                    }
+                    emit = rg == 0 && u == 0;                   // sample lt-1 goes out after the barrier
+                    if (emit) { wavp = c.wav ? c.wav + (size_t)sl.row * c.Lout + lt - 1 : nullptr;
+                                mulp = c.mulaw ? c.mulaw + (size_t)sl.row * c.Lout + lt - 1 : nullptr; xraw = x; }
                 }
                 x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
                 const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
-                const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
-                const float *bh = m.b_hh + unit;
-                hi = hl_index(Hr, sg, unit);
                 ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
-                gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
-                bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
-                hold = first ? 0.f : hin[hi];                   // a new utterance starts from h = 0
+                if (!m.gc_replay) {
+                    const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
+                    gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
+                }
+                hold = first ? 0.f : hprev;                     // a new utterance starts from h = 0
             }
+            if (rg == 0 && wave == 0) ((float4 *)mt)[lane] = mtl;
+            AR_STAMP(tid == 0, 0, 2);
         }
         __syncthreads();
         // cell update (PyTorch GRUCell equations, gate order r, z, n), K quarters summed in fixed order
+        if (emit) {                                  // network_vocoder.py:78 output: the sample the candidates decided
+            if (wavp) *wavp = m.n_cls <= 256 ? mt[xraw] : m.mulaw_tab[xraw];
+            if (mulp) *mulp = xraw;
+        }
         if (active) {
             // the slot's previous occupant left its state in the MFMA operand: W_hh . 0 = 0 on a first step
             const float gr = first ? 0.f : ((red[g][0][u][b] + red[g][1][u][b]) + red[g][2][u][b]) + red[g][3][u][b];
@@ -413,6 +490,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
             hout[hi] = (1.0f - z) * n + z * hold;
         }
+        AR_STAMP(tid == 0, 0, 3);
     }
 }
 
@@ -440,44 +518,27 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
     bool active = false, first = false;
     float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
     size_t hi = 0;
+    // (1a) first level of the cell update's operand chain: everything with a fixed address (as in ar_gru_kernel)
+    const int gbt = bt0 + q;
+    const int sg = (gbt < nbt ? gbt : nbt - 1) * 16 + b;
+    Cand16 cd;
+    ArSlot sl = ArSlot{-1, 0, 0, 0u};
+    ArCall c = ArCall{};
+    float hprev = 0.f;
     if (gate_wave) {
-        const int bt = bt0 + q;
-        const int sg = (bt < nbt ? bt : nbt - 1) * 16 + b;
-        Cand16 cd;                                                           // requested first: its 32 registers are
-        load_candidates16(m, sg, cd);                                        // dead again before the fragments arrive
-        const ArCall c = *cp;
-        const int t = c.t_base + t_local;
-        const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
-        const int lt = t - sl.t0;
-        const int xc = merge_candidates16(cd);
-        active = bt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
-        first = lt == 0;
-        if (active) {
-            int x;
-            if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
-            else if (first) x = m.n_cls / 2;
-            else {
-                x = xc;
-                if (rg == 0 && u == 0) {
-                    if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
-                    if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
-                }
-            }
-            x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
-            const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
-            const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
-            const float *bh = m.b_hh + unit;
-            hi = hl_index(Hr, sg, unit);
-            ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
-            gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
-            bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
-            hold = first ? 0.f : hin[hi];
-        }
+        load_candidates16(m, sg, cd);
+        sl = m.cur[sg];
+        c = *cp;
+        const float *bh = m.b_hh + unit;
+        bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
+        hi = hl_index(Hr, sg, unit);
+        hprev = hin[hi];
+        const float *gc = m.gcur + (size_t)sg * 3 * Hr + unit;
+        gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
     }
     __builtin_amdgcn_sched_barrier(0);
-    // (2) requests: this wave's weight fragment, this thread's share of state tile 0
-    // (state first: vmcnt retires in order, so the staging barrier then waits for the state only
-    // and the weight fragments keep streaming in underneath it)
+    // (2) requests: this thread's share of state tile 0 (state before weights: vmcnt retires in order, so the
+    // staging barrier waits for the state only and the weight fragments keep streaming in underneath it)
     const int t4 = Hr * 4;                                                   // float4 per state tile
     const float4 *src = (const float4 *)hin + (size_t)bt0 * t4;
     float4 st[4];
@@ -486,6 +547,35 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
         const int i = tid + 1024 * j;
         st[j] = i < t4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // (1b) second level: x picks the Gemb row; it comes back ahead of this wave's weight fragments
+    if (gate_wave) {
+        const int t = c.t_base + t_local;
+        const int lt = t - sl.t0;
+        active = gbt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
+        first = lt == 0;
+        if (active) {
+            int x;
+            if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
+            else if (first) x = m.n_cls / 2;
+            else {
+                x = merge_candidates16(cd);
+                if (rg == 0 && u == 0) {
+                    if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
+                    if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
+                }
+            }
+            x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
+            const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
+            ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
+            if (!m.gc_replay) {
+                const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
+                gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
+            }
+            hold = first ? 0.f : hprev;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float4 wf[SW];
     load_wfrag<SW>(m.Wf_hh, rg, 4, kq, lane, wf);
     __builtin_amdgcn_sched_barrier(0);
@@ -544,10 +634,11 @@ template <int SW>
 __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
     __shared__ float red[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
+    AR_STAMP(tid == 0, 1, 0);
     const float *h = m.hbuf + (size_t)((t_local + 1) & 1) * nbt * m.Hr * 16;
     float4 wf[SW], hv[SW];
     load_wfrag<SW>(m.Wf_fc1, rg, 4, wave, lane, wf);
-    load_hfrag<SW>(h, m.Hr, bt, wave, lane, hv);
+    load_hfrag<SW>(h, m.Hr, bt, wave, lane, bt == nbt - 1 ? m.live_last : 16, hv);
     const int row = 16 * rg + (tid >> 4);
     const float bias = m.b_fc1[row];
     __builtin_amdgcn_sched_barrier(0);
@@ -556,11 +647,13 @@ __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__
     const f32x4 acc = mfma_frag<SW>(wf, hv);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    AR_STAMP(tid == 0, 1, 1);
     __syncthreads();
     const int rr = tid >> 4, bb = tid & 15;
     float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
     v += bias;
     if (valid) m.a1[hl_index(m.Hf, bt * 16 + bb, row)] = v > 0.f ? v : 0.f;
+    AR_STAMP(tid == 0, 1, 3);
 }
 
 // Philox4x32-10, word `k & 3` of counter (t, utt, k >> 2, 0): the sampling protocol's stream.
@@ -583,15 +676,16 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     __shared__ float red[4][16][17];
     __shared__ float sc[16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
+    AR_STAMP(tid == 0, 2, 0);
     float4 wf[4], hv[4];
     load_wfrag<4>(m.Wf_fc2, rg, 4, wave, lane, wf);
-    load_hfrag<4>(m.a1, m.Hf, bt, wave, lane, hv);
+    load_hfrag<4>(m.a1, m.Hf, bt, wave, lane, bt == (int)gridDim.y - 1 ? m.live_last : 16, hv);
     const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;      // bg = decode slot
     const float bias = m.b_fc2[cls];
     __builtin_amdgcn_sched_barrier(0);
     const ArCall c = *cp;
     const int t = c.t_base + t_local;
-    const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + bg];
+    const ArSlot sl = m.cur[bg];
     const int lt = t - sl.t0;
     // noise of (class, utterance, sample) while the loads fly
     const unsigned w = philox_word((unsigned)lt, sl.utt, (unsigned)(cls >> 2), (unsigned)c.seed,
@@ -602,6 +696,7 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     const f32x4 acc = mfma_frag<4>(wf, hv);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    AR_STAMP(tid == 0, 2, 1);
     __syncthreads();
     float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
     v += bias;
@@ -617,9 +712,27 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
         m.cand_s[(size_t)bg * 16 + rg] = best;
         m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
     }
+    AR_STAMP(tid == 0, 2, 3);
 }
 
 __global__ void ar_advance_kernel(ArCall *c, int n) { c->t_base += n; }
+// Between replays (and once before the first): the slot row of the replay that starts at t_base, and -- when a
+// slot stays on one conditioning frame per replay (gc_replay) -- that frame's Gcond row per slot.
+// One workgroup per decode slot.
+__global__ __launch_bounds__(256) void ar_next_row_kernel(ArModel m, const ArCall *__restrict__ cp) {
+    const int sg = blockIdx.x;
+    const ArCall c = *cp;
+    const int r = c.t_base / c.S;
+    if (sg >= c.Sp || r >= c.n_rep) return;
+    const ArSlot sl = c.slots[(size_t)r * c.Sp + sg];
+    if (threadIdx.x == 0) m.cur[sg] = sl;
+    if (!m.gc_replay || sl.row < 0 || c.t_base < sl.t0) return;
+    const int f = (c.t_base - sl.t0) / m.upsample;
+    if (f >= c.F) return;
+    const float4 *src = (const float4 *)(c.Gcond + ((size_t)sl.row * c.F + f) * 3 * m.Hr);
+    float4 *dst = (float4 *)(m.gcur + (size_t)sg * 3 * m.Hr);
+    for (int i = threadIdx.x; i < 3 * m.Hr / 4; i += 256) dst[i] = src[i];
+}
 
 // Bounded delay (~cycles shader clocks): offsets the second tile group by about half a sample step.
 __global__ void ar_delay_kernel(int cycles) {
@@ -636,7 +749,7 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
     const int sg = blockIdx.x * blockDim.x + threadIdx.x;
     const ArCall c = *cp;
     if (sg >= c.Sp || c.inputs) return;
-    const ArSlot sl = c.slots[(size_t)(c.t_base / c.S) * c.Sp + sg];
+    const ArSlot sl = m.cur[sg];
     if (sl.row < 0) return;
     const int end = sl.t0 + sl.len;
     if (end <= c.t_base || end > c.t_base + c.S) return;
@@ -694,9 +807,9 @@ struct vqcpc_vocoder {
     // step overlaps the other's fc1/fc2; there is no edge between them inside a graph.
     struct Group {
         ArCall *call = nullptr;          // device
-        DevBuf har, a1, cand_s, cand_k, slot_tab;
-        std::map<int, hipGraphExec_t> graphs;   // key: tiles in the group
-        const void *baked[4] = {nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
+        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur;
+        std::map<int, hipGraphExec_t> graphs;   // key: (tiles in the group, live columns of the last tile, lead6)
+        const void *baked[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
     } grp[2];
     int two_groups = 1;                  // 0 = always one group
     hipStream_t side_stream = nullptr;
@@ -725,7 +838,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     for (auto &g : v->grp) {
         for (auto &kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
         if (g.call) (void)hipFree(g.call);
-        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab};
+        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur};
         for (DevBuf *b : gb) b->release();
     }
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
@@ -910,9 +1023,10 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     for (int i = 0; i < n; ++i) {
         switch (SW) {
 #define CASE(k) case k: \
-            if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt); \
+            if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt); \
             else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt); \
-            else hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
+            else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
+            else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
             hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
@@ -922,6 +1036,7 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     }
     hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, call, n);
+    hipLaunchKernelGGL(ar_next_row_kernel, dim3(nbt * 16), dim3(256), 0, s, m, (const ArCall *)call);
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
 }
@@ -997,6 +1112,8 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         }
         TRY(v->grp[g].slot_tab.reserve(table[g].size() * sizeof(ArSlot)));
         HIP_TRY(hipMemcpyAsync(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), hipMemcpyHostToDevice, s));
+        TRY(v->grp[g].cur.reserve((size_t)Spg * sizeof(ArSlot)));
+        HIP_TRY(hipMemcpyAsync(v->grp[g].cur.p, table[g].data(), (size_t)Spg * sizeof(ArSlot), hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipStreamSynchronize(s));     // host vectors above die with this frame
     const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
@@ -1019,23 +1136,32 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         TRY(G.a1.reserve((size_t)nb * d.Hf * 16 * sizeof(float)));
         TRY(G.cand_s.reserve((size_t)Spg * 16 * sizeof(float)));
         TRY(G.cand_k.reserve((size_t)Spg * 16 * sizeof(int)));
+        TRY(G.gcur.reserve((size_t)Spg * 3 * Hr * sizeof(float)));
         HIP_TRY(hipMemsetAsync(G.har.p, 0, 2 * hsz, s));
         HIP_TRY(hipMemsetAsync(G.cand_s.p, 0, (size_t)Spg * 16 * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(G.cand_k.p, 0, (size_t)Spg * 16 * sizeof(int), s));
         ArCall &c = calls[g];
         c = ArCall{};
         c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
-        c.slots = G.slot_tab.as<ArSlot>(); c.S = S; c.Sp = Spg;
+        c.slots = G.slot_tab.as<ArSlot>(); c.S = S; c.Sp = Spg; c.n_rep = rep[g] > 0 ? rep[g] : 1;
         c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = gmax[g]; c.nbt = nb; c.seed = seed; c.t_base = 0;
         HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
         ArModel &m = models[g];
         m = ArModel{};
         m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.b_fc1 = v->b_fc1;
         m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
-        m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>();
+        m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>(); m.cur = G.cur.as<ArSlot>(); m.gcur = G.gcur.as<float>();
+        m.gc_replay = d.upsample_t % S == 0;
+        {
+            const int live = (n_slots - slot0[g] < Spg ? n_slots - slot0[g] : Spg) - (nb - 1) * 16;
+            m.live_last = live < 1 ? 1 : (live > 16 ? 16 : live);
+        }
+        m.lead6 = n_grp == 2 && nb <= 2;
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
     HIP_TRY(hipStreamSynchronize(s));     // calls[] is a stack-lifetime host buffer
+    for (int g = 0; g < n_grp; ++g)       // replay 0's slot row and Gcond rows
+        hipLaunchKernelGGL(ar_next_row_kernel, dim3(tiles[g] * 16), dim3(256), 0, s, models[g], (const ArCall *)v->grp[g].call);
 
     HIP_TRY(hipEventRecord(v->ev0, s));
     if (v->use_graph) {
@@ -1043,13 +1169,14 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         for (int g = 0; g < n_grp; ++g) {
             auto &G = v->grp[g];
             // a graph bakes its ArModel (buffer pointers): drop cached graphs if a workspace moved
-            const void *now[4] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p};
+            const void *now[6] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p};
             if (memcmp(G.baked, now, sizeof now) != 0) {
                 for (auto &kv : G.graphs) (void)hipGraphExecDestroy(kv.second);
                 G.graphs.clear();
                 memcpy(G.baked, now, sizeof now);
             }
-            auto it = G.graphs.find(tiles[g]);
+            const int gkey = (tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6;     // the captured ArModel bakes all three
+            auto it = G.graphs.find(gkey);
             if (it == G.graphs.end()) {
                 hipGraph_t gr = nullptr;
                 hipGraphExec_t ge = nullptr;
@@ -1060,7 +1187,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
                 HIP_TRY(e);
                 HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
                 HIP_TRY(hipGraphDestroy(gr));
-                it = G.graphs.emplace(tiles[g], ge).first;
+                it = G.graphs.emplace(gkey, ge).first;
             }
             exec[g] = it->second;
         }
@@ -1131,9 +1258,10 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                 if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt); \
-                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); break;
                     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
