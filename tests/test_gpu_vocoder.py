@@ -118,7 +118,10 @@ def test_graph_replay_equals_eager_launches():
     voc.set_option("steps_per_graph", 160)
     c = voc.generate(z, spk, seed=3, utt_base=0, return_mulaw=True, max_steps=300)
     d = voc.generate(z, spk, seed=4, utt_base=0, return_mulaw=True, max_steps=300)
-    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0]) and torch.equal(a[1], c[1])
+    voc.set_option("steps_per_graph", 32)              # divides the 160-sample hop: several replays per conditioning
+    e = voc.generate(z, spk, seed=3, utt_base=0, return_mulaw=True, max_steps=300)     # frame, Gcond row cached per replay
+    voc.set_option("steps_per_graph", 160)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0]) and torch.equal(a[1], c[1]) and torch.equal(a[1], e[1])
     assert not torch.equal(a[1], d[1])
     assert a[0].shape == (2, 640) and a[0].abs().max() <= 1.0
 
