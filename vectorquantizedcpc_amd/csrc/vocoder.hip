@@ -30,7 +30,7 @@ __device__ __forceinline__ size_t hl_index(int K, int b, int k) {
 // Fragment-ordered weights.  For row group `rg` (16 rows, row_of(rg, i) or -1 = zero row),
 // K split over `ksplit` waves, super-step S = 16 consecutive k:
 //   Wf[((rg*ksplit + w)*SW + s)*64 + lane] (float4) = W[row_of(rg, lane&15)][16*S + 4*(lane>>4) + 0..3]
-// with S = w*SW + s.  rowmode: 0 plain (row = 16 rg + i), 3 GRU gates, 4 LSTM gates
+// with S = w*SW + s.  rowmode: 0 plain (row = 16 rg + i), 8 half groups (row = 8 rg + i, i < 8), 3 GRU gates, 4 LSTM gates
 // (row = gate*H + 4 rg + i%4, gate = i/4; rows >= G*4 are zero).
 // ------------------------------------------------------------------------------------------
 __global__ void build_wfrag_kernel(const float *__restrict__ W, int ldw, float *__restrict__ Wf, int n_rg,
@@ -47,6 +47,7 @@ __global__ void build_wfrag_kernel(const float *__restrict__ W, int ldw, float *
     const int i = lane & 15, kq = lane >> 4, S = w * SW + s;
     int row;
     if (rowmode == 0) row = 16 * rg + i;
+    else if (rowmode == 8) row = i < 8 ? 8 * rg + i : -1;
     else row = (i >> 2) < rowmode ? (i >> 2) * H + 4 * rg + (i & 3) : -1;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row >= 0) v = *(const float4 *)(W + (size_t)row * ldw + 16 * S + 4 * kq);
@@ -286,6 +287,7 @@ struct ArModel {               // constant per handle (baked into the captured g
     int live_last;             // decode slots in use in the last tile (1..16): lanes of dead columns re-read column 0
     int lead6;                 // ar_gru_kernel requests fragments 6 super-steps ahead instead of 3 (see there)
     const float *Wf_fc1, *b_fc1, *Wf_fc2, *b_fc2, *mulaw_tab;
+    const float *Wf_fc1h;      // fc1 in 8-row groups (few tiles in flight: twice the workgroups, half the weight bytes each)
     float *hbuf;               // [2][nbt][Hr*16]
     float *a1;                 // [nbt][Hf*16]
     float *cand_s;             // [Bpad][16] best score of each 16-class row group
@@ -629,17 +631,21 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
     }
 }
 
-// fc1 / fc2: grid = (row groups, utterance tiles) -- at most 16 x nbt workgroups.
-template <int SW>
+// fc1 / fc2: grid = (row groups, utterance tiles).  fc1 is bound by the bytes one CU pulls (57 KB of weights +
+// 57 KB of state per workgroup at ~70 GB/s): with ROWS = 8 a workgroup owns 8 output rows -- the other 8 rows of
+// the MFMA tile are dead lanes that re-read row 0 (exactly one 128-B line less per 16-lane group) -- so twice the
+// workgroups pull 28 + 57 KB each.  Used while few tiles are in flight (launch_ar_steps).
+template <int SW, int ROWS>
 __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
     __shared__ float red[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
     AR_STAMP(tid == 0, 1, 0);
     const float *h = m.hbuf + (size_t)((t_local + 1) & 1) * nbt * m.Hr * 16;
     float4 wf[SW], hv[SW];
-    load_wfrag<SW>(m.Wf_fc1, rg, 4, wave, lane, wf);
+    load_wfrag<SW>(ROWS == 8 ? m.Wf_fc1h : m.Wf_fc1, rg, 4, wave, (lane & 15) < ROWS ? lane : (lane & 48), wf);
     load_hfrag<SW>(h, m.Hr, bt, wave, lane, bt == nbt - 1 ? m.live_last : 16, hv);
-    const int row = 16 * rg + (tid >> 4);
+    const bool own = (tid >> 4) < ROWS;
+    const int row = own ? ROWS * rg + (tid >> 4) : 0;
     const float bias = m.b_fc1[row];
     __builtin_amdgcn_sched_barrier(0);
     const ArCall c = *cp;
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__
     const int rr = tid >> 4, bb = tid & 15;
     float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
     v += bias;
-    if (valid) m.a1[hl_index(m.Hf, bt * 16 + bb, row)] = v > 0.f ? v : 0.f;
+    if (valid && own) m.a1[hl_index(m.Hf, bt * 16 + bb, row)] = v > 0.f ? v : 0.f;
     AR_STAMP(tid == 0, 1, 3);
 }
 
@@ -800,7 +806,7 @@ struct vqcpc_vocoder {
     float *code_emb = nullptr, *spk_emb = nullptr;
     float *p_wih[2] = {}, *p_bih[2] = {}, *p_bhh[2] = {}, *p_wf[2] = {};   // per layer, both directions stacked
     float *w_cond = nullptr, *b_ih = nullptr, *Gemb = nullptr;
-    float *Wf_hh = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
+    float *Wf_hh = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *Wf_fc1h = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
     float *mulaw_tab = nullptr;
     // A decode call runs as 1 or 2 independent TILE GROUPS (disjoint utterance tiles, own state,
     // own call record, own captured graph).  Two groups run on two streams so that one group's GRU
@@ -846,7 +852,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->ev_join) (void)hipEventDestroy(v->ev_join);
     float *ptrs[] = {v->code_emb, v->spk_emb, v->p_wih[0], v->p_wih[1], v->p_bih[0], v->p_bih[1], v->p_bhh[0],
                      v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh, v->b_hh,
-                     v->Wf_fc1, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
+                     v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len};
     for (DevBuf *b : bufs) b->release();
@@ -895,6 +901,7 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     TRY(vq_gemm_chain(emb, de, w_emb, nullptr, v->Gemb, 3 * Hr, w->n_cls, 3 * Hr, de, de, 0));
     TRY(build_wfrag(w->ar_w_hh, Hr, Hr / 4, Hr, 4, 3, Hr, &v->Wf_hh));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 16, Hr, 4, 0, 0, &v->Wf_fc1));
+    TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 8, Hr, 4, 8, 0, &v->Wf_fc1h));
     TRY(build_wfrag(w->fc2_weight, w->Hf, w->n_cls / 16, w->Hf, 1, 0, 0, &v->Wf_fc2));
     TRY(dcopy(&v->b_fc1, w->fc1_bias, w->Hf));
     TRY(dcopy(&v->b_fc2, w->fc2_bias, w->n_cls));
@@ -1027,7 +1034,9 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
             else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt); \
             else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
             else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
-            hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); break;
+            if (nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
+            else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
+            break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
             default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
@@ -1148,7 +1157,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
         ArModel &m = models[g];
         m = ArModel{};
-        m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.b_fc1 = v->b_fc1;
+        m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
         m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
         m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>(); m.cur = G.cur.as<ArSlot>(); m.gcur = G.gcur.as<float>();
         m.gc_replay = d.upsample_t % S == 0;
@@ -1262,7 +1271,9 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                     else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt); \
                     else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
-                    else hipLaunchKernelGGL((ar_fc1_kernel<k>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); break;
+                    else if (c.nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    break;
                     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
                     default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
