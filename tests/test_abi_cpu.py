@@ -51,6 +51,13 @@ def test_no_cpu_fallback():
     voc = V.Vocoder(V.ConfVocoder()).eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         voc.generate(torch.zeros(1, 4, dtype=torch.long), torch.zeros(1, dtype=torch.long))
+    from vectorquantizedcpc_amd import loudness, preprocess         # the front-end drop-ins too
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        preprocess.wave_to_mel(torch.zeros(16000))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loudness.Meter(16000).integrated_loudness(torch.zeros(16000))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loudness.normalize.loudness(torch.zeros(16000), -20.0, -23.0)
 
 
 def test_product_never_imports_oracle():
