@@ -30,6 +30,23 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().vqcpc_abi_version() == 1
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/vqcpc.h is the drop-in boundary: it must compile as C99 with the calls INTEGRATION.md shows."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('''#include "vqcpc.h"
+#include <stddef.h>
+int use(vqcpc_encoder *enc, vqcpc_vocoder *voc, float *p, int64_t *i, void *s) {
+    int rc = vqcpc_encoder_encode(enc, p, 1, 32, VQCPC_CONV_AUTO, p, NULL, i, NULL, s);
+    rc |= vqcpc_vocoder_generate(voc, i, i, 1, 16, NULL, 13u, 0u, NULL, p, NULL, 0, s);
+    return rc;
+}
+''')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_state_dict_surface_matches_reference():
     enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
     sd = synth.encoder_state_dict()
