@@ -174,7 +174,19 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if launched:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL
+        # RCCL prints a version banner on stdout when its communicator comes up (at the first collective):
+        # send file descriptor 1 to stderr until then, so that stdout carries the one JSON line only
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N"
 
     enc, voc = build_models(dev)
