@@ -30,7 +30,7 @@ __device__ __forceinline__ size_t hl_index(int K, int b, int k) {
 // Fragment-ordered weights.  For row group `rg` (16 rows, row_of(rg, i) or -1 = zero row),
 // K split over `ksplit` waves, super-step S = 16 consecutive k:
 //   Wf[((rg*ksplit + w)*SW + s)*64 + lane] (float4) = W[row_of(rg, lane&15)][16*S + 4*(lane>>4) + 0..3]
-// with S = w*SW + s.  rowmode: 0 plain (row = 16 rg + i), 8 half groups (row = 8 rg + i, i < 8), 3 GRU gates, 4 LSTM gates
+// with S = w*SW + s.  rowmode: 0 plain (row = 16 rg + i), 8 half groups (row = 8 rg + i, i < 8), 16 GRU gate tiles (rg = 3 blk + gate: that gate of units 16 blk + i), 3 GRU gates, 4 LSTM gates
 // (row = gate*H + 4 rg + i%4, gate = i/4; rows >= G*4 are zero).
 // ------------------------------------------------------------------------------------------
 __global__ void build_wfrag_kernel(const float *__restrict__ W, int ldw, float *__restrict__ Wf, int n_rg,
@@ -48,6 +48,7 @@ __global__ void build_wfrag_kernel(const float *__restrict__ W, int ldw, float *
     int row;
     if (rowmode == 0) row = 16 * rg + i;
     else if (rowmode == 8) row = i < 8 ? 8 * rg + i : -1;
+    else if (rowmode == 16) row = (rg % 3) * H + 16 * (rg / 3) + i;
     else row = (i >> 2) < rowmode ? (i >> 2) * H + 4 * rg + (i & 3) : -1;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row >= 0) v = *(const float4 *)(W + (size_t)row * ldw + 16 * S + 4 * kq);
@@ -282,6 +283,7 @@ extern "C" int vqcpc_debug_ar_stamps(unsigned long long *out) {
 
 struct ArModel {               // constant per handle (baked into the captured graph)
     const float *Wf_hh, *b_hh, *Gemb;
+    const float *Wf_hh16;      // W_hh in gate-major 16-row tiles (large-batch kernel: no padding rows)
     float *gcur;               // [Sp][3Hr] the Gcond row every slot uses during the replay in flight (gc_replay)
     int gc_replay;             // 1: upsample % steps_per_graph == 0, so a slot stays on one conditioning frame per replay
     int live_last;             // decode slots in use in the last tile (1..16): lanes of dead columns re-read column 0
@@ -496,138 +498,151 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
     }
 }
 
-// Large-batch GRU step (>= 4 utterance tiles in flight).  The wave-specialised kernel above re-reads
+// Large-batch GRU step (>= 8 utterance tiles in flight).  The wave-specialised kernel above re-reads
 // the state tile once per row group; at many tiles the per-CU L2 read rate (~65 GB/s) is the limit
-// (DESIGN "what bounds K7a").  Here one 1024-thread workgroup owns FOUR row groups and TWO tiles:
-// the two state tiles (2 x 57 KB) are staged ONCE in LDS and shared by the 16 waves
-// (wave = row group x K quarter), weights stay in registers: 342 KB per 8 (row group, tile) units
-// instead of 8 x 86 KB.  Grid = (Hr/16, ceil(nbt/2)).
+// (DESIGN "what bounds K7a"), and behind it the MFMA pipe: 16 waves x 112 MFMAs = 6.8 us per SIMD when every
+// 16-row MFMA tile carries 4 padding rows.  Here one 1024-thread workgroup owns 16 hidden units and TWO tiles:
+//  * the two state tiles (2 x 57 KB) are staged ONCE in LDS and shared by all MFMA waves;
+//  * the 48 gate rows are three FULL 16-row tiles (r, z, n of the 16 units: fragment layout Wf_hh16), so 12
+//    waves (gate x K quarter) do the MFMAs -- 25 % fewer MFMAs and weight bytes (172 KB) than padded 12-row groups;
+//  * the 4 oldest waves do nothing but the cell update's operand chain and the update itself (2 units per lane).
+// Per-row arithmetic is unchanged (same K quarters, same accumulator pairs): bit-identical to ar_gru_kernel.
+// Grid = (Hr/16, ceil(nbt/2)).
+// staging of one state tile by all 1024 threads: request / store halves (the barrier is the caller's)
+__device__ __forceinline__ void big_stage_load(const float4 *src, int t4, int tid, bool on, float4 (&st)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
+        st[j] = (on && i < t4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void big_stage_store(float4 *dst, int t4, int tid, const float4 (&st)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
+        if (i < t4) dst[i] = st[j];
+    }
+}
+
 template <int SW>
 __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Hr = m.Hr;
     float4 *hs = (float4 *)smem;                                             // [2][Hr*4] float4 = two state tiles
-    float (*red)[4][4][16][17] = (float (*)[4][4][16][17])(smem + (size_t)2 * Hr * 16 * sizeof(float));   // [tile][rg][kq]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = wave >> 2, kq = wave & 3;
-    const int rg = blockIdx.x * 4 + r, bt0 = blockIdx.y * 2, nb = nbt - bt0 < 2 ? nbt - bt0 : 2;
+    float (*red)[3][4][16][17] = (float (*)[3][4][16][17])(smem + (size_t)2 * Hr * 16 * sizeof(float));   // [tile][gate][kq][unit][slot]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x, bt0 = blockIdx.y * 2, nb = nbt - bt0 < 2 ? nbt - bt0 : 2;
     const size_t hsz = (size_t)nbt * Hr * 16;
     const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
     float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
-
-    // (1) cell-update inputs of (row group r, tile q = wave & 1) for waves with (wave & 2) == 0
-    const bool gate_wave = (wave & 2) == 0;                                  // 8 of 16 waves: (r, q) = (wave >> 2, wave & 1)
-    const int q = wave & 1, u = lane >> 4, b = lane & 15, unit = 4 * rg + u;
-    bool active = false, first = false;
-    float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
-    size_t hi = 0;
-    // (1a) first level of the cell update's operand chain: everything with a fixed address (as in ar_gru_kernel)
-    const int gbt = bt0 + q;
-    const int sg = (gbt < nbt ? gbt : nbt - 1) * 16 + b;
-    Cand16 cd;
-    ArSlot sl = ArSlot{-1, 0, 0, 0u};
-    ArCall c = ArCall{};
-    float hprev = 0.f;
-    if (gate_wave) {
-        load_candidates16(m, sg, cd);
-        sl = m.cur[sg];
-        c = *cp;
-        const float *bh = m.b_hh + unit;
-        bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
-        hi = hl_index(Hr, sg, unit);
-        hprev = hin[hi];
-        const float *gc = m.gcur + (size_t)sg * 3 * Hr + unit;
-        gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // (2) requests: this thread's share of state tile 0 (state before weights: vmcnt retires in order, so the
-    // staging barrier waits for the state only and the weight fragments keep streaming in underneath it)
     const int t4 = Hr * 4;                                                   // float4 per state tile
     const float4 *src = (const float4 *)hin + (size_t)bt0 * t4;
     float4 st[4];
+
+    // The two roles are separate code paths (their registers never coexist); both pass the same three barriers.
+    if (wave < 4) {
+        // ---- cell-update waves: tile q, units 16 blk + 8 uh + 4 p + u (p = 0, 1), slot b
+        const int q = wave & 1, uh = wave >> 1, u = lane >> 4, b = lane & 15;
+        const int gbt = bt0 + q;
+        const int sg = (gbt < nbt ? gbt : nbt - 1) * 16 + b;
+        float ge[2][3] = {}, gc[2][3], bh[2][3], hold[2] = {0.f, 0.f}, hprev[2];
+        size_t hi[2];
+        // first level of the operand chain: everything with a fixed address (as in ar_gru_kernel)
+        Cand16 cd;
+        load_candidates16(m, sg, cd);
+        const ArSlot sl = m.cur[sg];
+        const ArCall c = *cp;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = tid + 1024 * j;
-        st[j] = i < t4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // (1b) second level: x picks the Gemb row; it comes back ahead of this wave's weight fragments
-    if (gate_wave) {
+        for (int p = 0; p < 2; ++p) {
+            const int unit = 16 * blk + 8 * uh + 4 * p + u;
+            const float *pb = m.b_hh + unit, *pg = m.gcur + (size_t)sg * 3 * Hr + unit;
+            bh[p][0] = pb[0]; bh[p][1] = pb[Hr]; bh[p][2] = pb[2 * Hr];
+            gc[p][0] = pg[0]; gc[p][1] = pg[Hr]; gc[p][2] = pg[2 * Hr];
+            hi[p] = hl_index(Hr, sg, unit);
+            hprev[p] = hin[hi[p]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        big_stage_load(src, t4, tid, true, st);
+        __builtin_amdgcn_sched_barrier(0);
+        // second level: x picks the Gemb rows
         const int t = c.t_base + t_local;
         const int lt = t - sl.t0;
-        active = gbt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
-        first = lt == 0;
+        const bool active = gbt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
+        const bool first = lt == 0;
         if (active) {
             int x;
             if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
             else if (first) x = m.n_cls / 2;
             else {
                 x = merge_candidates16(cd);
-                if (rg == 0 && u == 0) {
+                if (blk == 0 && uh == 0 && u == 0) {             // emit sample lt-1 (network_vocoder.py:78 output)
                     if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
                     if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
                 }
             }
             x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
-            const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
-            ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
-            if (!m.gc_replay) {
-                const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
-                gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int unit = 16 * blk + 8 * uh + 4 * p + u;
+                const float *pe = m.Gemb + (size_t)x * 3 * Hr + unit;
+                ge[p][0] = pe[0]; ge[p][1] = pe[Hr]; ge[p][2] = pe[2 * Hr];
+                if (!m.gc_replay) {
+                    const float *pg = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
+                    gc[p][0] = pg[0]; gc[p][1] = pg[Hr]; gc[p][2] = pg[2 * Hr];
+                }
+                hold[p] = first ? 0.f : hprev[p];
             }
-            hold = first ? 0.f : hprev;
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float4 wf[SW];
-    load_wfrag<SW>(m.Wf_hh, rg, 4, kq, lane, wf);
-    __builtin_amdgcn_sched_barrier(0);
-    // (3) stage tile 0, then request tile 1 so that it streams in underneath tile 0's MFMAs
+        big_stage_store(hs, t4, tid, st);
+        __syncthreads();
+        big_stage_load(src + t4, t4, tid, nb > 1, st);
+        big_stage_store(hs + t4, t4, tid, st);
+        __syncthreads();
+        __syncthreads();
+        if (active) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = tid + 1024 * j;
-        if (i < t4) hs[i] = st[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = tid + 1024 * j;
-        st[j] = (nb > 1 && i < t4) ? src[t4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // (4) W_hh h: this wave's row group and K quarter against tile 0, then tile 1
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-        if (qq == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = tid + 1024 * j;
-                if (i < t4) hs[t4 + i] = st[j];
+            for (int p = 0; p < 2; ++p) {
+                const int ul = 8 * uh + 4 * p + u;
+                const float gr = first ? 0.f : ((red[q][0][0][ul][b] + red[q][0][1][ul][b]) + red[q][0][2][ul][b]) + red[q][0][3][ul][b];
+                const float gz = first ? 0.f : ((red[q][1][0][ul][b] + red[q][1][1][ul][b]) + red[q][1][2][ul][b]) + red[q][1][3][ul][b];
+                const float gn = first ? 0.f : ((red[q][2][0][ul][b] + red[q][2][1][ul][b]) + red[q][2][2][ul][b]) + red[q][2][3][ul][b];
+                const float rr = sigmoidf_((ge[p][0] + gc[p][0]) + (gr + bh[p][0]));
+                const float z = sigmoidf_((ge[p][1] + gc[p][1]) + (gz + bh[p][1]));
+                const float n = tanhf((ge[p][2] + gc[p][2]) + rr * (gn + bh[p][2]));
+                hout[hi[p]] = (1.0f - z) * n + z * hold[p];
             }
-            __syncthreads();
         }
-        const float4 *hp = hs + (size_t)qq * t4 + (size_t)kq * SW * 64 + lane;
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    } else {
+        // ---- MFMA waves: gate tile gt (r, z, n of the 16 units), K quarter kq
+        const int gt = (wave - 4) >> 2, kq = (wave - 4) & 3;
+        big_stage_load(src, t4, tid, true, st);              // state before weights: vmcnt retires in order, so the
+        float4 wf[SW];                                       // staging barrier waits for the state only
+        load_wfrag<SW>(m.Wf_hh16, blk * 3 + gt, 4, kq, lane, wf);
+        __builtin_amdgcn_sched_barrier(0);
+        big_stage_store(hs, t4, tid, st);
+        __syncthreads();
+        big_stage_load(src + t4, t4, tid, nb > 1, st);       // tile 1 streams in underneath tile 0's MFMAs
 #pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            const float4 hv = hp[s * 64];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv.x, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv.y, a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv.z, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv.w, a1, 0, 0, 0);
+        for (int qq = 0; qq < 2; ++qq) {
+            if (qq == 1) {
+                big_stage_store(hs + t4, t4, tid, st);
+                __syncthreads();
+            }
+            const float4 *hp = hs + (size_t)qq * t4 + (size_t)kq * SW * 64 + lane;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const float4 hv = hp[s * 64];
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, hv.x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, hv.y, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, hv.z, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, hv.w, a1, 0, 0, 0);
+            }
+            const f32x4 acc = a0 + a1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[qq][gt][kq][(lane >> 4) * 4 + k][lane & 15] = acc[k];
         }
-        const f32x4 acc = a0 + a1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) red[qq][r][kq][(lane >> 4) * 4 + k][lane & 15] = acc[k];
-    }
-    __syncthreads();
-    // (5) cell update
-    if (active) {
-        const float gr = first ? 0.f : ((red[q][r][0][u][b] + red[q][r][1][u][b]) + red[q][r][2][u][b]) + red[q][r][3][u][b];
-        const float gz = first ? 0.f : ((red[q][r][0][4 + u][b] + red[q][r][1][4 + u][b]) + red[q][r][2][4 + u][b]) + red[q][r][3][4 + u][b];
-        const float gn = first ? 0.f : ((red[q][r][0][8 + u][b] + red[q][r][1][8 + u][b]) + red[q][r][2][8 + u][b]) + red[q][r][3][8 + u][b];
-        const float rr = sigmoidf_((ge0 + gc0) + (gr + bh0));
-        const float z = sigmoidf_((ge1 + gc1) + (gz + bh1));
-        const float n = tanhf((ge2 + gc2) + rr * (gn + bh2));
-        hout[hi] = (1.0f - z) * n + z * hold;
+        __syncthreads();
     }
 }
 
@@ -806,7 +821,7 @@ struct vqcpc_vocoder {
     float *code_emb = nullptr, *spk_emb = nullptr;
     float *p_wih[2] = {}, *p_bih[2] = {}, *p_bhh[2] = {}, *p_wf[2] = {};   // per layer, both directions stacked
     float *w_cond = nullptr, *b_ih = nullptr, *Gemb = nullptr;
-    float *Wf_hh = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *Wf_fc1h = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
+    float *Wf_hh = nullptr, *Wf_hh16 = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *Wf_fc1h = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
     float *mulaw_tab = nullptr;
     // A decode call runs as 1 or 2 independent TILE GROUPS (disjoint utterance tiles, own state,
     // own call record, own captured graph).  Two groups run on two streams so that one group's GRU
@@ -823,7 +838,7 @@ struct vqcpc_vocoder {
     DevBuf series, gi, out0, cond, gcond, hseq, len;
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
-    int big_min_tiles = 8;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never)
+    int big_min_tiles = 6;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never)
     bool big_attr_set = false;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -851,7 +866,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->ev_fork) (void)hipEventDestroy(v->ev_fork);
     if (v->ev_join) (void)hipEventDestroy(v->ev_join);
     float *ptrs[] = {v->code_emb, v->spk_emb, v->p_wih[0], v->p_wih[1], v->p_bih[0], v->p_bih[1], v->p_bhh[0],
-                     v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh, v->b_hh,
+                     v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh, v->Wf_hh16, v->b_hh,
                      v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len};
@@ -900,6 +915,7 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     TRY(dcopy(&emb, w->ar_embedding, (size_t)w->n_cls * de));
     TRY(vq_gemm_chain(emb, de, w_emb, nullptr, v->Gemb, 3 * Hr, w->n_cls, 3 * Hr, de, de, 0));
     TRY(build_wfrag(w->ar_w_hh, Hr, Hr / 4, Hr, 4, 3, Hr, &v->Wf_hh));
+    if (Hr % 16 == 0) TRY(build_wfrag(w->ar_w_hh, Hr, 3 * (Hr / 16), Hr, 4, 16, Hr, &v->Wf_hh16));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 16, Hr, 4, 0, 0, &v->Wf_fc1));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 8, Hr, 4, 8, 0, &v->Wf_fc1h));
     TRY(build_wfrag(w->fc2_weight, w->Hf, w->n_cls / 16, w->Hf, 1, 0, 0, &v->Wf_fc2));
@@ -1016,7 +1032,7 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
     // large-batch GRU kernel: >= big_min_tiles tiles in flight, Hr a multiple of 16, LDS fits
-    const size_t big_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 4 * 4 * 16 * 17 * sizeof(float);
+    const size_t big_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool big = v->big_min_tiles > 0 && nbt >= v->big_min_tiles && v->d.Hr % 16 == 0 && big_lds <= 160 * 1024;
     if (big && !v->big_attr_set) {
         switch (SW) {
@@ -1157,7 +1173,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
         ArModel &m = models[g];
         m = ArModel{};
-        m.Wf_hh = v->Wf_hh; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
+        m.Wf_hh = v->Wf_hh; m.Wf_hh16 = v->Wf_hh16; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
         m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
         m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>(); m.cur = G.cur.as<ArSlot>(); m.gcur = G.gcur.as<float>();
         m.gc_replay = d.upsample_t % S == 0;
@@ -1257,7 +1273,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     const ArModel m = v->last_model;
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
-    const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 4 * 4 * 16 * 17 * sizeof(float);
+    const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
