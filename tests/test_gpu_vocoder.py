@@ -201,3 +201,21 @@ def test_tile_groups_and_large_batch_kernel_are_bit_identical():
     assert int((ref != 0).sum()) > 10000
     for name, m in outs.items():
         assert torch.equal(m, ref), name
+
+
+def test_default_paths_at_many_batch_sizes_equal_single_utterance_calls():
+    """Default options at batch sizes that take different code paths -- one tile with dead columns (5), two
+    groups (40: a 2-tile and a 1-tile group), the large-batch kernel with a partly filled last tile (100),
+    two large-batch groups (200) -- against calls on single utterances with the same sampling-stream ids."""
+    voc, _ = vocoder()
+    for B in (5, 40, 100, 200):
+        z = synth.randint("mb/z%d" % B, (B, 2), 512).cuda()
+        spk = (torch.arange(B) * 7 % 102).cuda()
+        n_codes = [1 + (i % 2) for i in range(B)]
+        ids = list(range(1000, 1000 + B))
+        m = voc.generate(z, spk, n_codes=n_codes, seed=21, utt_ids=ids, return_mulaw=True)[1]
+        for i in sorted({0, 1, B // 2, B - 2, B - 1}):
+            one = voc.generate(z[i:i + 1, : n_codes[i]], spk[i:i + 1], seed=21, utt_ids=[ids[i]], return_mulaw=True)[1]
+            L = 320 * n_codes[i]
+            assert torch.equal(m[i, :L], one[0, :L]), (B, i)
+            assert not m[i, L:].any(), (B, i)
