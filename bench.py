@@ -9,16 +9,26 @@ Vocoder.generate (B x 32 000 samples).  The per-GPU batch is BASELINE.json confi
 waveforms are gathered on rank 0 over RCCL inside the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no torch.distributed.run environment, this process starts the N ranks
+itself (fresh children of `python -m torch.distributed.run`, before it makes any GPU call),
+relays rank 0's JSON line and exits with the children's status.  Under torch.distributed.run
+(RANK / WORLD_SIZE set) it is one of the ranks.
 
 Rank 0 prints ONE JSON line.  Extra keys next to the contract's: `roofline` (decode step vs the
-fp32 MFMA peak), `cpu_baseline` (the PyTorch-CPU port of the same path on this box's host
-cores, bounded sample), `encoder` (BASELINE configs[1], 64 x 128 frames) and `single_utterance`
-(configs[2], 1 x 32 000 samples).
+fp32 MFMA peak), `cpu_baseline` (the PyTorch-CPU port of the same path on this box's host cores,
+bounded samples, 1 thread and all usable cores), `encoder` (BASELINE configs[1], 64 x 128
+frames, + configs[0]'s 1 x 200), `single_utterance` (configs[2], 1 x 32 000 samples),
+`one_gpu_256` (configs[3]'s whole batch on one GPU, with its own roofline), `manifest`
+(configs[4] stand-in), `teacher_forced` (SURVEY 8f-4 shape); for N > 1 `rccl_ranks` and `gather`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -37,8 +47,94 @@ HBM_PEAK_GBS = 8000.0
 # + fc1 229 376 + fc2 65 536 MAC, + the conditioning half of W_ih once per 160-sample frame
 FLOP_PER_SAMPLE = 2 * (2408448 + 688128 + 229376 + 65536) + 2 * 688128 / 160.0
 FLOP_PER_FRAME = 2555904        # encoder, per output frame without the LSTM
+GRU_MAC = 2408448               # W_hh MACs per sample: the dominant kernel's algorithmic work
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+KERNEL_SOURCES = ("vectorquantizedcpc_amd/csrc/vocoder.hip", "vectorquantizedcpc_amd/csrc/common.h")
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def kernel_source_sha():
+    """Identity of the decode kernels a PMC measurement belongs to (.git does not travel to the GPU box)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as fresh children (no GPU call in this process)
+# ------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """Parent of a multi-GPU run.  torch.cuda.device_count() does not initialise the GPU on this image;
+    nothing else here touches it.  Returns the exit status for sys.exit."""
+    if not args.selftest_spawn:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for but this node exposes {n_dev} GPU(s); "
+                  f"nothing was run (use --gpus {max(n_dev, 1)} here)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:])))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                       # relay rank 0's one JSON line, pass anything else to stderr
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit status {rc})", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 3
+    print(line, flush=True)
+    return 0
+
+
+def selftest_rank(args):
+    """CPU rehearsal of the N > 1 plumbing (tests/test_bench_spawn_cpu.py): gloo ranks, a barrier, the
+    gather on rank 0 and the JSON relay -- no kernels, nothing measured."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        if args.selftest_spawn == 2 and rank == world - 1:
+            raise SystemExit(7)                   # a failing rank must fail the parent
+        wav = torch.full((2, 8), float(rank))
+        out = [torch.empty_like(wav) for _ in range(world)] if rank == 0 else None
+        dist.barrier()
+        dist.gather(wav, out, dst=0)
+        if rank == 0:
+            ok = all(float(o[0, 0]) == r for r, o in enumerate(out))
+            print("stray line on stdout", flush=True)      # must not reach the parent's stdout
+            print(json.dumps({"metric": "selftest", "value": float(ok), "n_gpus": world, "rccl_ranks": dist.get_world_size(),
+                              "backend": "gloo", "selftest": True}), flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
 def build_models(dev):
     enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
     enc.load_state_dict(synth.encoder_state_dict())
@@ -68,57 +164,103 @@ def timed(fn, steps, warmup, dev, world):
     return dt
 
 
-def host_cores():
-    """Cores this process may actually use (cgroup / affinity aware), capped at the GPU box's share."""
+def wall(fn, dev, reps=1):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / reps, out
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline: the PyTorch-CPU port on this box's host cores
+# ------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """os.cpu_count(), lscpu's physical core count, and the threads this process may actually use
+    (affinity and cgroup quota; no other cap)."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        info["lscpu_model"] = kv.get("Model name")
+        info["lscpu_cores"] = int(kv.get("Core(s) per socket", "0")) * int(kv.get("Socket(s)", "0")) or None
+        info["lscpu_threads_per_core"] = int(kv.get("Thread(s) per core", "0")) or None
+    except (OSError, ValueError, subprocess.SubprocessError):
+        info["lscpu_cores"] = None
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    info["affinity"] = n
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
+            info["cgroup_quota_cpus"] = int(quota) / int(period)
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, 16))
+    info["usable_threads"] = max(1, n)
+    return info
 
 
-def cpu_baseline(n_utt, budget_s=12.0):
-    """PyTorch-CPU port of the same decode loop on this box's host cores, bounded sample."""
-    from oracle import torch_ref
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    tv = torch_ref.TorchVocoder(synth.vocoder_state_dict())
-    z = synth.randint("bench/codes", (n_utt, 100), 512)
-    spk = torch.arange(n_utt) % 102
-    noise = torch_ref.make_noise(n_utt, 40, synth.SEED)
-    tv.generate(z, spk, seed=synth.SEED, n_steps=10, noise=noise[:, :10])   # warm-up (thread pool, MKL)
-    t0 = time.perf_counter()
-    tv.generate(z, spk, seed=synth.SEED, n_steps=40, noise=noise)    # calibration
-    per_step = (time.perf_counter() - t0) / 40
-    n_steps = int(max(80, min(3200, budget_s / max(per_step, 1e-6))))
-    log(f"cpu baseline: {cores} threads, ~{per_step * 1e3:.2f} ms/step, timing {n_steps} steps")
-    noise = torch_ref.make_noise(n_utt, n_steps, synth.SEED)          # RNG of the protocol: not timed
-    reps, dt = 0, 0.0
-    while dt < budget_s and reps < 8:                                 # ~10-15 s of CPU work in all
+def median_time(fn, warmup=3, reps=10):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(reps):
         t0 = time.perf_counter()
-        tv.generate(z, spk, seed=synth.SEED, n_steps=n_steps, noise=noise)
-        dt += time.perf_counter() - t0
-        reps += 1
-    n_steps *= reps
-    esd = synth.encoder_state_dict()
-    mel = synth.mel("bench/c2", 64, 128)
-    torch_ref.encoder_encode(esd, mel, want_c=False)
-    t1 = time.perf_counter()
-    for _ in range(5):
-        torch_ref.encoder_encode(esd, mel, want_c=False)
-    de = (time.perf_counter() - t1) / 5
-    return {"value": n_utt * n_steps / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n_utt} concurrent utterances x {n_steps} decode steps of the same workload "
-                      f"(PyTorch-CPU ops, {cores} threads; prenet included), {dt:.1f} s",
-            "encoder_frames_per_s": 64 * 64 / de}
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts)
 
 
+def cpu_baseline(n_utt):
+    """Legs of SURVEY 8(d): encode C1 (1 x 200) and C2 (64 x 128), the AR loop at B = 1 (C3: 2 000 steps in
+    10 timed chunks, extrapolated linearly to 32 000) and at B = n_utt (the bench workload), each with
+    torch.set_num_threads(1) and (all usable threads), warm-up 3, median of 10.  `value` = the bench
+    workload's leg on all usable threads."""
+    from oracle import torch_ref
+    info = host_cpu_info()
+    esd, vsd = synth.encoder_state_dict(), synth.vocoder_state_dict()
+    tv = torch_ref.TorchVocoder(vsd)
+    mel1, mel2 = synth.mel("bench/c1", 1, 200), synth.mel("bench/c2", 64, 128)
+    zB = synth.randint("bench/codes", (n_utt, 100), 512)
+    z1 = synth.randint("bench/c3", (1, 100), 512)
+    spkB, spk1 = torch.arange(n_utt) % 102, torch.zeros(1, dtype=torch.long)
+    chunk1, chunkB = 200, 40                                       # decode steps per timed repetition
+    noise1 = torch_ref.make_noise(1, chunk1, synth.SEED)           # the protocol's noise: generated outside the timing
+    noiseB = torch_ref.make_noise(n_utt, chunkB, synth.SEED)
+    cond1, condB = tv.condition(z1, spk1), tv.condition(zB, spkB)  # prenet once (it is < 0.1 % of a real call)
+    legs = {}
+    t_all = time.perf_counter()
+    for threads in sorted({1, info["usable_threads"]}):
+        torch.set_num_threads(threads)
+        tag = f"{threads}t"
+        d = median_time(lambda: torch_ref.encoder_encode(esd, mel1, want_c=True))
+        legs[f"c1_encode_1x200_{tag}"] = {"ms": d * 1e3, "frames_per_s": 100 / d}
+        d = median_time(lambda: torch_ref.encoder_encode(esd, mel2, want_c=True))
+        legs[f"c2_encode_64x128_{tag}"] = {"ms": d * 1e3, "frames_per_s": 4096 / d}
+        d = median_time(lambda: torch_ref.encoder_encode(esd, mel2, want_c=False))
+        legs[f"c2_encode_64x128_no_context_{tag}"] = {"ms": d * 1e3, "frames_per_s": 4096 / d}
+        d = median_time(lambda: tv.generate(z1, spk1, seed=synth.SEED, n_steps=chunk1, noise=noise1, cond=cond1))
+        legs[f"c3_decode_b1_{tag}"] = {"us_per_step": d / chunk1 * 1e6, "samples_per_s": chunk1 / d,
+                                       "seconds_for_32000_samples_extrapolated": d / chunk1 * 32000,
+                                       "timed": f"median of 10 x {chunk1} steps (2 000 steps), extrapolated linearly"}
+        d = median_time(lambda: tv.generate(zB, spkB, seed=synth.SEED, n_steps=chunkB, noise=noiseB, cond=condB))
+        legs[f"decode_b{n_utt}_{tag}"] = {"us_per_step": d / chunkB * 1e6, "samples_per_s": n_utt * chunkB / d}
+        log(f"cpu baseline, {threads} thread(s): " + ", ".join(f"{k} {list(v.values())[0]:.4g}" for k, v in legs.items() if k.endswith(tag)))
+    total = time.perf_counter() - t_all
+    nt = info["usable_threads"]
+    main = legs[f"decode_b{n_utt}_{nt}t"]
+    return {"value": main["samples_per_s"], "unit": "samples/s", "cores": nt, "kind": "port",
+            "sample": f"{n_utt} concurrent utterances x {chunkB}-step chunks of the same decode workload, warm-up 3, median of 10 "
+                      f"(PyTorch-CPU ops, {nt} threads; all legs together {total:.1f} s of CPU work)",
+            "encoder_frames_per_s": legs[f"c2_encode_64x128_no_context_{nt}t"]["frames_per_s"],
+            "host": info, "legs": legs}
+
+
+# ------------------------------------------------------------------------------------------
 def synthetic_manifest(n, seed=synth.SEED):
     """BASELINE configs[4] stand-in: the reference ships no test-set manifest (datasets are
     git-ignored), so lengths are drawn log-normally between 1 and 10 s (seeded), speakers round-robin."""
@@ -146,9 +288,52 @@ def run_manifest(enc, voc, dev, n_utt, max_batch):
             "samples_per_s": samples / dt, "realtime_factor_16k": samples / 16000.0 / dt}
 
 
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+def gru_roofline(voc, n_utt, step_us):
+    """`roofline` object for the GRU-step kernel of the LAST generate() call: HIP events around 2000
+    back-to-back launches on the launch stream (vqcpc_vocoder_kernel_times)."""
+    gru_us, fc1_us, fc2_us, per_launch, kind = voc.kernel_times(2000)
+    per_launch = min(int(per_launch), n_utt)                 # utterances one launch covers (one tile group)
+    names = {0: "ar_gru_kernel<14,1> (one tile)", 1: "ar_gru_kernel<14,2> (two tiles per workgroup)",
+             2: "ar_gru_big_kernel<14> (LDS-staged state, full 16-row gate tiles)",
+             3: "ar_gru16_kernel<14> (full 16-row gate tiles, small batch)"}
+    flop = 2.0 * GRU_MAC * per_launch
+    achieved = flop / (gru_us * 1e-6) / 1e12
+    step_tflops = FLOP_PER_SAMPLE * n_utt / (step_us * 1e-6) / 1e12
+    # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
+    alg_bytes = 4.0 * (GRU_MAC + per_launch * (2 * 896 + 2 * 3 * 896))
+    return {"bound": "mfma", "kernel": names.get(int(kind), "ar_gru") + ": W_hh h for all utterances + GRU cell update",
+            "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+            "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "flop_per_launch": flop,
+            "avg_launch_us": gru_us, "utterances_per_launch": per_launch,
+            "how": "HIP events on the launch stream around 2000 back-to-back launches (includes the ~1.5 us "
+                   "dependent-launch boundary)",
+            "other_kernels_us": {"ar_fc1_kernel": fc1_us, "ar_fc2_kernel": fc2_us},
+            "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
+                            "flop": FLOP_PER_SAMPLE * n_utt,
+                            "how": "HIP events around the whole decode loop / samples per utterance"}}
+
+
+def attach_traffic(roof):
+    """HBM-side bytes per launch of the dominant kernel come from separate `rocprofv3 --pmc` passes
+    (tools/collect_traffic.py writes profiles/r02_pmc_traffic.json with the sha of the kernel sources it
+    measured).  A file measured on other kernel sources or another batch is refused, not reported."""
+    roof["traffic_source"] = "none"
+    try:
+        pmc = json.load(open(TRAFFIC_JSON))
+    except (OSError, ValueError):
+        return
+    if pmc.get("kernel_source_sha") != kernel_source_sha():
+        roof["traffic_source"] = f"stale: {os.path.relpath(TRAFFIC_JSON, ROOT)} was measured on other kernel sources; re-run tools/collect_traffic.py"
+        return
+    if pmc.get("utterances") != roof["utterances_per_launch"]:
+        roof["traffic_source"] = "offline file covers another batch size"
+        return
+    roof["traffic"] = pmc["traffic_bytes_per_launch"]
+    roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; mostly Infinity-Cache hits)"
+    roof["traffic_source"] = (f"offline: tools/collect_traffic.py -> {os.path.relpath(TRAFFIC_JSON, ROOT)} "
+                              f"(kernel sources {pmc['kernel_source_sha']}, {pmc.get('launch_mode', '?')} launches, "
+                              f"kernel {pmc.get('kernel', '?')})")
+    roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
 
 
 def main():
@@ -158,19 +343,32 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--utterances-per-gpu", type=int, default=32)
     ap.add_argument("--frames", type=int, default=200, help="mel frames per utterance (200 = 2 s = 32 000 samples)")
-    ap.add_argument("--manifest", type=int, default=0, help="also run a synthetic ragged manifest of this many utterances")
-    ap.add_argument("--manifest-batch", type=int, default=128, help="decode slots of the manifest workload")
+    ap.add_argument("--manifest", type=int, default=512, help="synthetic ragged manifest of this many utterances (0 = skip)")
+    ap.add_argument("--manifest-batch", type=int, default=256, help="decode slots of the manifest workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--selftest-spawn", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torch.distributed.run
+    if not launched and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if launched and args.selftest_spawn:
+        return selftest_rank(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torch.distributed.run
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; pass the same N to both "
+              "(or run plain `python bench.py --gpus N`, which starts its own ranks)", file=sys.stderr)
+        sys.exit(2)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.device_count() <= local:
+            print(f"bench.py: rank {rank} has no GPU {local} on this node", file=sys.stderr)
+            sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if launched:
@@ -187,10 +385,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N"
 
     enc, voc = build_models(dev)
-    if os.environ.get("VQCPC_BENCH_NO_GRAPH"):           # counter collection (rocprofv3 --pmc) needs plain launches
+    if os.environ.get("VQCPC_BENCH_NO_GRAPH"):           # eager launches of the same kernels (debugging)
         voc.set_option("use_graph", 0)
     Bp, T = args.utterances_per_gpu, args.frames
     n_total = Bp * world
@@ -216,23 +413,8 @@ def main():
     value = samples / dt
     loop_ms, n_loop = voc.last_timing()                       # HIP events around the last decode loop
     step_us = loop_ms * 1e3 / max(n_loop, 1)
-    gru_us, fc1_us, fc2_us, per_launch = voc.kernel_times(2000)   # HIP events around back-to-back launches
-    per_launch = min(int(per_launch), Bp)                     # utterances one launch covers (tile group)
-    # dominant kernel = the GRU step: algorithmic FLOP per launch = W_hh mat-vec for every utterance it covers
-    gru_flop = 2.0 * 2408448 * per_launch
-    achieved = gru_flop / (gru_us * 1e-6) / 1e12
-    step_tflops = FLOP_PER_SAMPLE * Bp / (step_us * 1e-6) / 1e12
-    # HBM-side bytes per launch of that kernel: collected offline with rocprofv3 --pmc (separate
-    # passes, gfx950 FETCH_SIZE correction applied) -- profiles/r01_pmc_traffic.json, same batch only
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pmc.get("utterances") == per_launch:
-            traffic = pmc["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
-    gru_bytes = 4.0 * (2408448 + per_launch * (2 * 896 + 2 * 3 * 896))
+    roof = gru_roofline(voc, Bp, step_us)
+    attach_traffic(roof)
 
     result = {
         "metric": "audio samples/sec (WaveRNN-style decode, convert.py path: encode + generate)",
@@ -245,58 +427,80 @@ def main():
                    "parallelism": f"utterance-sharded x{world}, one RCCL gather"},
         "realtime_factor_16k": value / 16000.0,
         "realtime_factor_16k_per_gpu": value / 16000.0 / world,
-        "roofline": {"bound": "mfma", "kernel": "ar_gru_kernel<14> (GRU step: W_hh h for all utterances + cell update)",
-                     "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; mostly Infinity-Cache hits)",
-                     "algorithmic_bytes_per_launch": gru_bytes,
-                     "flop_per_launch": gru_flop, "avg_launch_us": gru_us, "utterances_per_launch": per_launch,
-                     "how": "HIP events on the launch stream around 2000 back-to-back launches (includes the "
-                            "~1.5 us dependent-launch boundary)",
-                     "other_kernels_us": {"ar_fc1_kernel": fc1_us, "ar_fc2_kernel": fc2_us},
-                     "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
-                                     "flop": FLOP_PER_SAMPLE * Bp,
-                                     "how": "HIP events around the whole decode loop / samples per utterance"}},
+        "roofline": roof,
     }
+    if launched:
+        # the exchange step alone: every rank's (Bp, L) fp32 waveforms to rank 0, max over ranks of 5 repetitions
+        wav = state["wav"]
+        out = [torch.empty_like(wav) for _ in range(world)] if rank == 0 else None
+        dist.gather(wav, out, dst=0)
+        gt = timed(lambda: dist.gather(wav, out, dst=0), 5, 1, dev, world) / 5
+        result["rccl_ranks"] = dist.get_world_size()
+        result["backend"] = dist.get_backend()
+        result["gather"] = {"bytes_per_rank": wav.numel() * 4, "bytes_total": wav.numel() * 4 * world, "ms": gt * 1e3,
+                            "how": "dist.gather of the step's waveforms to rank 0 alone, barrier-bracketed, mean of 5"}
 
-    if rank == 0 and world == 1 and not args.no_extras:
-        # BASELINE configs[1]: encoder conv+VQ forward, batch 64 x 128 frames
+    solo = rank == 0 and world == 1
+    if solo and not args.no_extras:
+        # BASELINE configs[1]: encoder conv+VQ forward, batch 64 x 128 frames; configs[0]'s 1 x 200 next to it
         m2 = synth.mel("bench/c2", 64, 128).to(dev)
-        for _ in range(3):
-            enc.encode_indices(m2)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            enc.encode_indices(m2)
-        torch.cuda.synchronize(dev)
-        de = (time.perf_counter() - t0) / reps
+        enc.encode_indices(m2)
+        de, _ = wall(lambda: enc.encode_indices(m2), dev, 20)
         fps = 64 * 64 / de
         alg_bytes = 64 * 80 * 128 * 4 + 5132544 + 4096 * (64 * 4 + 8)
+        m1 = synth.mel("bench/c1", 1, 200).to(dev)
+        enc.encode_indices(m1)
+        d1, _ = wall(lambda: enc.encode_indices(m1), dev, 50)
+        enc.encode(m1)
+        d1c, _ = wall(lambda: enc.encode(m1), dev, 20)
         result["encoder"] = {"workload": "BASELINE configs[1]: 64 x 80 x 128 mel -> 4096 code frames",
                              "frames_per_s": fps, "ms": de * 1e3,
                              "tflops": FLOP_PER_FRAME * fps / 1e12,
                              "frac_fp32_peak": FLOP_PER_FRAME * fps / 1e12 / FP32_PEAK_TFLOPS,
                              "algorithmic_GBps": alg_bytes / de / 1e9,
-                             "frac_hbm_peak": alg_bytes / de / 1e9 / HBM_PEAK_GBS}
+                             "frac_hbm_peak": alg_bytes / de / 1e9 / HBM_PEAK_GBS,
+                             "c1_1x200_ms": d1 * 1e3, "c1_1x200_with_context_ms": d1c * 1e3}
         # BASELINE configs[2]: one utterance of 32 000 samples
         z1 = synth.randint("bench/c3", (1, 100), 512).to(dev)
         s1 = torch.zeros(1, dtype=torch.long, device=dev)
         voc.generate(z1, s1, seed=synth.SEED, utt_base=0, max_steps=2000)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        voc.generate(z1, s1, seed=synth.SEED, utt_base=0)
-        torch.cuda.synchronize(dev)
-        d1 = time.perf_counter() - t0
+        d1, _ = wall(lambda: voc.generate(z1, s1, seed=synth.SEED, utt_base=0), dev)
         result["single_utterance"] = {"workload": "BASELINE configs[2]: 1 utterance x 32 000 samples",
-                                      "samples_per_s": 32000 / d1, "realtime_factor_16k": 2.0 / d1}
-    if rank == 0 and world == 1 and args.manifest > 0:
+                                      "samples_per_s": 32000 / d1, "realtime_factor_16k": 2.0 / d1,
+                                      "us_per_sample": d1 / 32000 * 1e6}
+        # BASELINE configs[3] whole (256 utterances) on ONE GPU: it fits, so this is the single-GPU ceiling
+        n256 = 256
+        mel256 = torch.cat([synth.mel(f"bench/utt{i % 64}", 1, T) for i in range(n256)]).to(dev)
+        spk256 = (torch.arange(n256) % 102).to(dev)
+
+        def step256():
+            return voc.generate(enc.encode_indices(mel256), spk256, seed=synth.SEED, utt_base=0)
+        step256()
+        d256, _ = wall(step256, dev)
+        ms256, n256_loop = voc.last_timing()
+        r256 = gru_roofline(voc, n256, ms256 * 1e3 / max(n256_loop, 1))
+        r256["traffic_source"] = "none"
+        result["one_gpu_256"] = {"workload": f"BASELINE configs[3] unsharded: {n256} utterances x {L} samples on one GPU "
+                                             "(two tile groups of 128 on two streams)",
+                                 "samples_per_s": n256 * L / d256, "realtime_factor_16k": n256 * L / 16000.0 / d256,
+                                 "ms_per_step": d256 * 1e3, "roofline": r256}
+        del mel256
+        # teacher-forced Vocoder.forward at the reference's training shape (vocoder.py:51-66)
+        melf = synth.mel("fwd/mel", 32, 32).to(dev)
+        idxf = enc.encode_indices(melf)
+        xf = synth.randint("fwd/x", (32, 5119), 256).to(dev)
+        spkf = (torch.arange(32) % 102).to(dev)
+        voc(xf, idxf, spkf)
+        dtf, _ = wall(lambda: voc(xf, idxf, spkf), dev, 3)
+        result["teacher_forced"] = {"workload": "Vocoder.forward (32, 5119) -> (32, 5119, 256) energies (vocoder.py:62 shape)",
+                                    "ms": dtf * 1e3, "samples_per_s": 32 * 5119 / dtf}
+    if solo and args.manifest > 0:
         log(f"manifest workload: {args.manifest} utterances")
         result["manifest"] = run_manifest(enc, voc, dev, args.manifest, args.manifest_batch)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Bp)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if launched:
         dist.destroy_process_group()
 

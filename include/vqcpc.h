@@ -104,6 +104,12 @@ int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int
 int vqcpc_encoder_stage(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
                         int stage, float *out, void *stream);
 
+/* Replaces VQEmbeddingEMA.encode called on its own (model.py:103-115): x DEVICE (n_rows, z_dim) fp32 rows,
+ * 16-byte aligned -> z_q DEVICE (n_rows, z_dim) = codebook rows, idx DEVICE (n_rows) int64, first index wins
+ * ties.  The same kernel vqcpc_encoder_encode runs after the front end. */
+int vqcpc_encoder_vq_encode(vqcpc_encoder *enc, const float *x, int n_rows, float *z_q, int64_t *idx,
+                            void *stream);
+
 /* Replaces the eval branch of VQEmbeddingEMA.forward as used by Encoder.forward
  * (model.py:72-86, :117-155): from encode()'s z_pre / z_q / idx (n_rows = B*T/2) computes
  * z_st = x + (q - x) (DEVICE, n_rows*z_dim, or NULL), loss = 0.25*mse (DEVICE scalar) and
@@ -155,7 +161,7 @@ void vqcpc_vocoder_destroy(vqcpc_vocoder *voc);
  * stream fixed: class k of sample t of utterance u (= utt_ids[b], HOST (B), or utt_base + b when
  * utt_ids is NULL -- an utterance's stream does not depend on how utterances are batched) uses
  * w = Philox4x32-10(counter = (t, u, k >> 2, 0), key = seed)[k & 3],
- * g_k = -log(-log(((w >> 8) + 0.5) * 2^-24)), and x_t = first argmax_k (l_k + g_k).  Outputs DEVICE: wav (B, L) fp32 in [-1, 1] with
+ * g_k = -log(-log(((w >> 9) + 0.5) * 2^-23)) (uniform exact in fp32, strictly inside (0, 1)), and x_t = first argmax_k (l_k + g_k).  Outputs DEVICE: wav (B, L) fp32 in [-1, 1] with
  * L = 2*upsample_t*Tc, mu-law decoded (preprocess.py:30-35); mulaw (B, L) int64 class
  * indices or NULL.  max_steps > 0 stops after that many samples (tests). */
 int vqcpc_vocoder_generate(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
@@ -228,9 +234,10 @@ int vqcpc_loudness_normalize(vqcpc_loudness *m, float *wav, const int *lens, int
 
 /* Average wall time, in microseconds, of `reps` back-to-back launches of each per-sample kernel
  * of the decode loop on the state the last generate()/logits() call left (HIP events on
- * `stream`; synchronises it).  out_us[4] = {GRU step, fc1, fc2 + draw, decode slots one launch
- * covers (a call of 33..112 utterances runs as two independent tile groups)}.  Each time includes
- * this chip's ~1.5 us dependent-launch boundary. */
+ * `stream`; synchronises it).  out_us[5] = {GRU step, fc1, fc2 + draw, decode slots one launch
+ * covers (a call of 33..80 or >= 192 utterances runs as two independent tile groups), which GRU-step
+ * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel}.
+ * Each time includes this chip's ~1.5 us dependent-launch boundary. */
 int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 
 #ifdef __cplusplus

@@ -11,6 +11,6 @@ leg may import this package.  The product (``vectorquantizedcpc_amd``) never doe
 """
 from .ref import (  # noqa: F401
     build, lib, encoder_encode, vq_encode, vq_forward_stats, conv1d_k4s2, layernorm,
-    linear, lstm, sumsq64, philox4x32_10, sample_noise, mulaw_decode,
+    linear, lstm, sumsq64, philox4x32_10, sample_noise, noise_from_word, mulaw_decode,
     vocoder_generate, vocoder_condition, sample_from_logits,
 )

@@ -46,6 +46,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.orc_sumsq64.restype = C.c_float
         _lib.orc_sample_noise.restype = C.c_float
+        _lib.orc_noise_from_word.restype = C.c_float
+        _lib.orc_noise_from_word.argtypes = [C.c_uint32]
         _lib.orc_sample_noise.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         _lib.orc_sample_from_logits.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.orc_mulaw_decode.restype = C.c_float
@@ -200,6 +202,11 @@ def philox4x32_10(ctr, key):
 def sample_noise(seed, utterance, t, k):
     """Gumbel noise of class k, sample t, utterance `utterance` (see orc_sample_noise)."""
     return np.float32(lib().orc_sample_noise(int(seed), int(utterance), int(t), int(k)))
+
+
+def noise_from_word(w):
+    """Gumbel noise of one raw Philox word (the uniform conversion of the sampling protocol)."""
+    return np.float32(lib().orc_noise_from_word(int(w) & 0xFFFFFFFF))
 
 
 def mulaw_decode(s, bits=8):

@@ -36,9 +36,16 @@ def encoder_encode(sd, mel, want_c=True):
     return q, c, idx.view(z.shape[0], z.shape[1]), z
 
 
+def noise_from_words(w):
+    """uint32 Philox words -> Gumbel noise, the protocol's conversion: 23 bits + 1/2 is exact in fp32 and
+    strictly inside (0, 1) (a 24-bit form rounds to 1.0 at the top word: +inf noise)."""
+    uni = torch.from_numpy(((w >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0))
+    return -torch.log(-torch.log(uni))
+
+
 def make_noise(B, n_steps, seed, utt_base=0, chunk=256):
     """Gumbel noise (B, n_steps, 256) of the sampling protocol:
-    Philox(counter=(t, utt, k>>2, 0), key=seed)[k&3] -> ((w>>8)+0.5)*2^-24 -> -log(-log(u))."""
+    Philox(counter=(t, utt, k>>2, 0), key=seed)[k&3] -> ((w>>9)+0.5)*2^-23 -> -log(-log(u))."""
     out = torch.empty(B, n_steps, 256)
     for t0 in range(0, n_steps, chunk):
         n = min(chunk, n_steps - t0)
@@ -47,8 +54,7 @@ def make_noise(B, n_steps, seed, utt_base=0, chunk=256):
         ctr[:, 1] = np.repeat(np.arange(utt_base, utt_base + B, dtype=np.uint32), n * 64)
         ctr[:, 2] = np.tile(np.arange(64, dtype=np.uint32), B * n)
         w = synth.philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(B, n, 256)
-        uni = torch.from_numpy(((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0))
-        out[:, t0:t0 + n] = -torch.log(-torch.log(uni))
+        out[:, t0:t0 + n] = noise_from_words(w)
     return out
 
 
@@ -75,10 +81,11 @@ class TorchVocoder:
         return cond
 
     @torch.no_grad()
-    def generate(self, z, spk, seed, utt_base=0, n_steps=None, inputs=None, want_logits=False, noise=None):
+    def generate(self, z, spk, seed, utt_base=0, n_steps=None, inputs=None, want_logits=False, noise=None, cond=None):
         sd = self.sd
         B = z.shape[0]
-        cond = self.condition(z, spk)
+        if cond is None:                                   # bench.py's timed chunks pass the prenet output in
+            cond = self.condition(z, spk)
         total = self.up * cond.shape[1]
         n_steps = total if n_steps is None else min(n_steps, total)
         if noise is None:

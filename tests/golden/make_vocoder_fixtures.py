@@ -4,6 +4,8 @@
 
 The reference's vocoder arithmetic (third-party ``rnnms``) is absent offline, so these vectors come
 from this project's own CPU oracle and pin the SPEC against drift -- parity with ``rnnms`` is unpinned.
+(``vocoder_glue.npz`` is NOT made here: ``tools/gen_golden.py`` records it from the reference's own
+``network_vocoder.py`` with a capture stub for ``rnnms``.)
 
 Usage:  python tests/golden/make_vocoder_fixtures.py
 """
@@ -17,23 +19,6 @@ GOLD = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(GOLD))
 sys.path.insert(0, ROOT)
 from vectorquantizedcpc_amd import synth  # noqa: E402
-
-
-def glue_fixture():
-    """network_vocoder.py:69-77 glue layout, restated with torch ops on CPU and frozen as data.
-
-    (The reference module itself needs ``rnnms`` to import; SURVEY 8c verified this layout
-    against the reference with a capture stub.  Parity of the recurrence stays unpinned.)
-    """
-    sd = synth.vocoder_state_dict()
-    z = synth.randint("glue/z", (2, 5), 512)
-    spk = synth.randint("glue/spk", (2,), 102)
-    ze = torch.nn.functional.embedding(z, sd["code_embedding.weight"])
-    zu = torch.nn.functional.interpolate(ze.transpose(1, 2), scale_factor=2).transpose(1, 2)
-    se = torch.nn.functional.embedding(spk, sd["speaker_embedding.weight"])
-    series = torch.cat((zu, se.unsqueeze(1).expand(-1, zu.size(1), -1)), dim=-1)
-    np.savez_compressed(os.path.join(GOLD, "vocoder_glue.npz"), z=z.numpy(), speaker=spk.numpy(),
-                        series=series.numpy())
 
 
 def vocoder_selforacle():
@@ -53,6 +38,5 @@ def vocoder_selforacle():
 
 
 if __name__ == "__main__":
-    glue_fixture()
     vocoder_selforacle()
-    print("wrote vocoder_glue.npz, vocoder_selforacle.npz")
+    print("wrote vocoder_selforacle.npz")

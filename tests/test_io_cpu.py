@@ -49,3 +49,26 @@ def test_checkpoint_layouts(tmp_path):
     assert set(got.keys()) == set(vsd.keys())
     torch.save({"vocoder": vsd}, tmp_path / "voc.pt")                             # convert.py:45
     assert set(io.load_vocoder_checkpoint(tmp_path / "voc.pt").keys()) == set(vsd.keys())
+
+
+def test_vocoder_checkpoint_keys_are_matched_by_suffix_and_shape(tmp_path):
+    """The `rnnms.*` key names are this project's guess at the absent third-party module's layout: a checkpoint
+    whose module nests the GRUs differently still loads (unique suffix + shape), and one that does not fit
+    raises with expected-vs-found lists instead of loading partially."""
+    import pytest
+    vsd = synth.vocoder_state_dict()
+    renamed = {}
+    for k, v in vsd.items():
+        k2 = k.replace("rnnms.prenet.", "rnnms.prenet.net.").replace("rnnms.ar.rnn.", "rnnms.decoder.gru.")
+        k2 = k2.replace("rnnms.ar.fc1", "rnnms.decoder.fc1").replace("rnnms.ar.fc2", "rnnms.decoder.fc2")
+        renamed[k2.replace("rnnms.ar.embedding", "rnnms.decoder.embedding")] = v
+    assert set(renamed) != set(vsd)
+    torch.save({"vocoder": renamed}, tmp_path / "voc2.pt")
+    got = io.load_vocoder_checkpoint(tmp_path / "voc2.pt", expected=vsd)
+    assert list(got.keys()) == list(vsd.keys()) and all(torch.equal(got[k], vsd[k]) for k in vsd)
+    bad = dict(renamed)
+    bad.pop(next(k for k in bad if k.endswith("fc1.bias")))
+    bad["rnnms.something.else"] = torch.zeros(3)
+    with pytest.raises(KeyError) as ei:
+        io.remap_state_dict(bad, vsd)
+    assert "rnnms.ar.fc1.bias" in str(ei.value) and "rnnms.something.else" in str(ei.value)

@@ -112,6 +112,23 @@ def test_philox_known_answer():
     assert tuple(int(v) for v in synth.philox4x32_10(ctr[:1], (0, 0))[0]) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
 
 
+def test_sampling_noise_is_finite_for_every_word():
+    """The protocol's uniform, ((w >> 9) + 0.5) * 2^-23, is exact in fp32 and strictly inside (0, 1): the
+    extreme Philox words give finite Gumbel noise (a 24-bit form rounds to 1.0f at the top word -> +inf,
+    which would win the argmax whatever the logits are).  C oracle and torch port use the same conversion."""
+    from oracle import torch_ref
+    words = np.array([0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFE00, 0xFFFFFFFF], np.uint32)
+    c = np.array([oracle.noise_from_word(int(w)) for w in words], np.float32)
+    t = torch_ref.noise_from_words(words).numpy()
+    assert np.isfinite(c).all() and np.isfinite(t).all()
+    assert np.abs(c - t).max() <= 2e-6                       # libm vs ATen logf
+    u_max = (np.float32(0xFFFFFFFF >> 9) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    u_min = np.float32(0.5) * np.float32(1.0 / 8388608.0)
+    assert float(u_max) == 1.0 - 2.0 ** -24 and float(u_min) == 2.0 ** -24
+    assert c[0] < -2.5 and 16.0 < c[-1] < 17.0               # -log(-log(2^-24)) = -2.81, -log(-log(1 - 2^-24)) = 16.6
+    assert np.all(np.diff(c) >= 0)                           # monotone in the word
+
+
 def test_mulaw_decode_matches_reference_formula():
     """preprocess.py:30-35 evaluated in float64 numpy, as the reference does."""
     s = np.arange(256)
@@ -123,8 +140,11 @@ def test_mulaw_decode_matches_reference_formula():
 
 
 def test_vocoder_glue_matches_fixture(golden_dir):
-    """network_vocoder.py:69-77 layout: [:64] code emb twice per code, [64:] speaker emb."""
+    """network_vocoder.py:69-77 layout: [:64] code emb twice per code, [64:] speaker emb.  The fixture is what the
+    REFERENCE's own Vocoder.generate / Vocoder.forward handed to a capture stub standing in for rnnms
+    (tools/gen_golden.py::glue_fixture_from_reference)."""
     g = np.load(os.path.join(golden_dir, "vocoder_glue.npz"))
+    assert "reference network_vocoder.py" in str(g["source"])
     sd = synth.vocoder_state_dict()
     import ctypes as C
     z, spk = g["z"], g["speaker"]

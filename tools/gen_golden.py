@@ -10,10 +10,13 @@ path.  Fixtures are DATA only: case parameters, code indices, argmin margins, SH
 of the bit patterns of each stage, a few full rows, float64 checksums.  Nothing of the
 reference's source travels; the GPU box rebuilds inputs and weights from the seed.
 
-Vocoder half: the reference's arithmetic (third-party ``rnnms``) is absent, so there is
-nothing to import; ``vocoder_selforacle.npz`` / ``vocoder_glue.npz`` are produced by this
-project's own CPU oracle (``tests/golden/make_vocoder_fixtures.py``) and are labelled
-self-oracle (parity unpinned).
+Vocoder half: the reference's arithmetic (third-party ``rnnms``) is absent.  The wrapper's own
+glue (``network_vocoder.py:41-78``: embed, x2 nearest upsample, speaker broadcast, concat) IS
+importable once ``rnnms.networks.vocoder`` is replaced by an in-process capture stub:
+``vocoder_glue.npz`` records what the reference's ``Vocoder.generate`` / ``Vocoder.forward`` hand to
+``rnnms`` -- that pins the glue (a-9) by the reference, nothing more.  ``vocoder_selforacle.npz``
+comes from this project's own CPU oracle (``tests/golden/make_vocoder_fixtures.py``): self-oracle,
+parity unpinned.
 
 Usage:  python tools/gen_golden.py            (writes tests/golden/)
 """
@@ -103,6 +106,53 @@ def encoder_fixture(model, name, B, T, ln_affine, codebook):
           f"loss={out['loss']:.6g} ppl={out['perplexity']:.6g}")
 
 
+def glue_fixture_from_reference():
+    """Run the reference's own ``Vocoder.generate`` / ``Vocoder.forward`` (network_vocoder.py:41-78) with
+    ``rnnms.networks.vocoder`` replaced by a stub that records what it is called with."""
+    from dataclasses import dataclass
+    seen = {}
+
+    @dataclass
+    class ConfRNNMSVocoder:            # network_vocoder.py:24 only needs a default-constructible class
+        dim_i_feature: int = 128
+
+    class RNNMSVocoder(torch.nn.Module):
+        def __init__(self, conf):
+            super().__init__()
+
+        def forward(self, x, latent_series):                   # network_vocoder.py:67
+            seen["forward"] = (x.clone(), latent_series.clone())
+            return torch.zeros(x.shape[0], x.shape[1], 256)
+
+        def generate(self, z_spk_series):                      # network_vocoder.py:78
+            seen["generate"] = z_spk_series.clone()
+            return torch.zeros(z_spk_series.shape[0], 160 * z_spk_series.shape[1])
+
+    for name in ("rnnms", "rnnms.networks", "rnnms.networks.vocoder"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["rnnms.networks.vocoder"].ConfRNNMSVocoder = ConfRNNMSVocoder
+    sys.modules["rnnms.networks.vocoder"].RNNMSVocoder = RNNMSVocoder
+    import network_vocoder as nv                               # /root/reference (sys.path set by import_reference)
+    voc = nv.Vocoder(nv.ConfVocoder(512, 64, 102, 64))
+    sd = synth.vocoder_state_dict()
+    own = {k: sd[k] for k in ("code_embedding.weight", "speaker_embedding.weight")}
+    assert sorted(voc.state_dict().keys()) == sorted(own.keys())          # the stub has no parameters
+    voc.load_state_dict(own)
+    voc.eval()
+    z = synth.randint("glue/z", (2, 5), 512)
+    spk = synth.randint("glue/spk", (2,), 102)
+    x = synth.randint("glue/x", (2, 37), 256)
+    with torch.no_grad():
+        voc.generate(z, spk)
+        voc(x, z, spk)
+    series = seen["generate"]
+    assert series.shape == (2, 10, 128) and torch.equal(seen["forward"][1], series) and torch.equal(seen["forward"][0], x)
+    np.savez_compressed(os.path.join(GOLD, "vocoder_glue.npz"), z=z.numpy(), speaker=spk.numpy(),
+                        series=series.numpy(), x=x.numpy(),
+                        source=np.array("reference network_vocoder.py Vocoder.generate/forward, rnnms replaced by a capture stub"))
+    print("vocoder_glue: reference Vocoder.generate/forward hand rnnms a", tuple(series.shape), "series; forward passes x through")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     model = import_reference()
@@ -110,6 +160,7 @@ def main():
           "| cpu capability", torch.backends.cpu.get_cpu_capability(), "| threads", torch.get_num_threads())
     for name, args in ENCODER_CASES.items():
         encoder_fixture(model, name, *args)
+    glue_fixture_from_reference()
     print("wrote", sorted(os.listdir(GOLD)))
 
 

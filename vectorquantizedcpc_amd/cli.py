@@ -30,7 +30,8 @@ def _models(args, need_vocoder):
     voc = None
     if need_vocoder:
         voc = Vocoder(ConfVocoder())
-        voc.load_state_dict(synth.vocoder_state_dict() if args.random_init else io.load_vocoder_checkpoint(args.vocoder_checkpoint))
+        voc.load_state_dict(synth.vocoder_state_dict() if args.random_init else
+                            io.load_vocoder_checkpoint(args.vocoder_checkpoint, expected=voc.state_dict()))
         voc = voc.to(dev).eval()
     return enc, voc
 

@@ -657,6 +657,16 @@ extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, i
     return VQCPC_OK;
 }
 
+extern "C" int vqcpc_encoder_vq_encode(vqcpc_encoder *e, const float *x, int n_rows, float *z_q, int64_t *idx,
+                                       void *stream) {
+    VQ_REQUIRE(e && x && z_q && idx && n_rows > 0, "vqcpc_encoder_vq_encode: bad argument");
+    VQ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)z_q & 15) == 0, "vqcpc_encoder_vq_encode: rows must be 16-byte aligned");
+    hipLaunchKernelGGL(vq_encode_kernel, dim3((n_rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, n_rows,
+                       (const float4 *)e->cbfrag, e->codebook, e->e2, e->n_emb, idx, z_q);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
 extern "C" int vqcpc_encoder_stage(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode, int stage,
                                    float *out, void *stream) {
     VQ_REQUIRE(e && mel && out, "vqcpc_encoder_stage: null argument");

@@ -33,8 +33,9 @@ __global__ void mf_peak_kernel(const float *__restrict__ wav, const int *__restr
 }
 
 __global__ void mf_frame_kernel(const float *__restrict__ wav, const int *__restrict__ len, const unsigned *__restrict__ peak,
-                                int Lmax, int Tmax, int hop, int win, int Kp, float preemph, float *__restrict__ F) {
+                                int Lmax, int Tmax, int hop, int win, int Kp, float preemph, float *__restrict__ F, size_t rows) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= rows * Kp) return;                               // the grid is rounded up to 256 threads
     const int j = (int)(id % Kp);
     const size_t row = id / Kp;
     const int n = (int)(row % Tmax), b = (int)(row / Tmax);
@@ -72,8 +73,9 @@ __device__ __forceinline__ float ordered_val(unsigned k) {
 }
 
 __global__ void mf_db_kernel(float *__restrict__ melraw, const int *__restrict__ len, int Tmax, int hop, int n_mels, int nmp,
-                             unsigned *maxdb) {
+                             unsigned *maxdb, size_t rows) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= rows * nmp) return;
     const int m = (int)(id % nmp);
     const size_t row = id / nmp;
     const int n = (int)(row % Tmax), b = (int)(row / Tmax);
@@ -189,13 +191,13 @@ extern "C" int vqcpc_melfront_run(vqcpc_melfront *f, const float *wav, const int
     const int *dl = f->lens.as<int>();
     hipLaunchKernelGGL(mf_peak_kernel, dim3(64, B), dim3(256), 0, s, wav, dl, Lmax, f->peak.as<unsigned>());
     hipLaunchKernelGGL(mf_frame_kernel, dim3((unsigned)((rows * Kp + 255) / 256)), dim3(256), 0, s, wav, dl,
-                       f->peak.as<unsigned>(), Lmax, Tmax, f->hop, f->win, Kp, f->preemph, f->frames.as<float>());
+                       f->peak.as<unsigned>(), Lmax, Tmax, f->hop, f->win, Kp, f->preemph, f->frames.as<float>(), rows);
     TRY(vq_gemm_chain(f->frames.as<float>(), Kp, f->dftW, nullptr, f->spec.as<float>(), 2 * nbp, (int)rows, 2 * nbp, Kp, Kp, s));
     hipLaunchKernelGGL(mf_mag_kernel, dim3((unsigned)((rows * nbp + 255) / 256)), dim3(256), 0, s, f->spec.as<float>(),
                        f->nbins, nbp, f->mag.as<float>(), rows);
     TRY(vq_gemm_chain(f->mag.as<float>(), nbp, f->melW, nullptr, f->melraw.as<float>(), nmp, (int)rows, nmp, nbp, nbp, s));
     hipLaunchKernelGGL(mf_db_kernel, dim3((unsigned)((rows * nmp + 255) / 256)), dim3(256), 0, s, f->melraw.as<float>(), dl,
-                       Tmax, f->hop, f->n_mels, nmp, f->maxdb.as<unsigned>());
+                       Tmax, f->hop, f->n_mels, nmp, f->maxdb.as<unsigned>(), rows);
     const size_t nout = (size_t)B * f->n_mels * Tmax;
     hipLaunchKernelGGL(mf_final_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, f->melraw.as<float>(), dl,
                        f->maxdb.as<unsigned>(), Tmax, f->hop, f->n_mels, nmp, f->top_db, mel, B);

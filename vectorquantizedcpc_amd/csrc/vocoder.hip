@@ -711,7 +711,9 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     // noise of (class, utterance, sample) while the loads fly
     const unsigned w = philox_word((unsigned)lt, sl.utt, (unsigned)(cls >> 2), (unsigned)c.seed,
                                    (unsigned)(c.seed >> 32), cls & 3);
-    const float g = -logf(-logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f)));
+    // 23 random bits + 0.5: every value is exact in fp32 and strictly inside (0, 1) -- a 24-bit form rounds to 1.0f
+    // at w >> 8 == 0xFFFFFF, i.e. +inf noise that wins whatever the logit is
+    const float g = -logf(-logf(((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f)));
     const bool live = t < c.max_t && sl.row >= 0 && lt < sl.len;
     __builtin_amdgcn_sched_barrier(0);
     const f32x4 acc = mfma_frag<4>(wf, hv);
@@ -1303,6 +1305,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
         out_us[which] = ms * 1e3f / (float)reps;
     }
     out_us[3] = (float)(c.nbt * 16);       // decode slots one launch of the timed configuration covers
+    out_us[4] = c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f);    // which GRU-step kernel that configuration runs
     return VQCPC_OK;
 }
 

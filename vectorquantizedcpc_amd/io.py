@@ -66,13 +66,69 @@ def load_encoder_checkpoint(path) -> Dict[str, torch.Tensor]:
     return ck["encoder"] if "encoder" in ck else ck
 
 
-def load_vocoder_checkpoint(path) -> Dict[str, torch.Tensor]:
+def load_vocoder_checkpoint(path, expected: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """``checkpoint["vocoder"]`` (``convert.py:45``) or a Lightning checkpoint rooted at ``VocoderModel.model``
+    (``vocoder.py:47``), loaded without executing anything from the file.
+
+    ``expected`` = ``Vocoder(conf).state_dict()``: the key names under ``rnnms.*`` are this project's GUESS at
+    the absent third-party module's layout, so a real checkpoint is matched to them by
+    ``remap_state_dict`` (exact name, else unique suffix + shape) rather than trusted to ``load_state_dict``.
+    """
     ck = torch.load(path, map_location="cpu", weights_only=True)
-    if "vocoder" in ck:                       # convert.py:45
-        return ck["vocoder"]
-    if "state_dict" in ck:                    # Lightning checkpoint rooted at VocoderModel.model (vocoder.py:47)
-        return {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
-    return ck
+    if "vocoder" in ck:
+        sd = ck["vocoder"]
+    elif "state_dict" in ck:
+        sd = {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+    else:
+        sd = ck
+    return remap_state_dict(sd, expected) if expected is not None else sd
+
+
+def _suffixes(key: str):
+    parts = key.split(".")
+    for n in range(len(parts), 0, -1):                 # longest suffix first
+        yield ".".join(parts[-n:])
+
+
+def remap_state_dict(found: Dict[str, torch.Tensor], expected: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Rename the tensors of ``found`` to the keys of ``expected``.
+
+    An expected key takes the found key of the same name; otherwise the ONE unused found key that shares its
+    longest dotted suffix (``...prenet.net.weight_ih_l0`` for ``rnnms.prenet.weight_ih_l0``, at least the last
+    component) and has the same shape.  Anything ambiguous, missing or left over raises ``KeyError`` listing
+    expected versus found names and shapes -- never a silent partial load.
+    """
+    out, used = {}, set()
+    for k, t in expected.items():
+        if k in found and tuple(found[k].shape) == tuple(t.shape):
+            out[k] = found[k]
+            used.add(k)
+    problems = []
+    for k, t in expected.items():
+        if k in out:
+            continue
+        pick = None
+        for suf in _suffixes(k):
+            cands = [f for f in found if f not in used and (f == suf or f.endswith("." + suf))
+                     and tuple(found[f].shape) == tuple(t.shape)]
+            if len(cands) == 1:
+                pick = cands[0]
+                break
+            if len(cands) > 1:
+                problems.append(f"{k} {tuple(t.shape)}: ambiguous, candidates {sorted(cands)}")
+                break
+        if pick is not None:
+            out[k] = found[pick]
+            used.add(pick)
+        elif not any(p.startswith(k + " ") for p in problems):
+            problems.append(f"{k} {tuple(t.shape)}: no tensor with a matching name suffix and shape")
+    extra = [f"{f} {tuple(found[f].shape)}" for f in found if f not in used]
+    if problems or extra:
+        raise KeyError("checkpoint does not fit the module.\n  unresolved expected keys:\n    " + "\n    ".join(problems or ["-"])
+                       + "\n  unused checkpoint keys:\n    " + "\n    ".join(extra or ["-"])
+                       + "\n  expected: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in expected.items())
+                       + "\n  found: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in found.items()))
+    return out
 
 
 def read_test_metadata(dataset_root) -> List[Path]:

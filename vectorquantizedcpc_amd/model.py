@@ -8,6 +8,7 @@ Same constructor (``Encoder(conf: ConfEncoder)``, ``model.py:17-34``), same
 runs in ``libvqcpc_hip.so`` through the C ABI of ``include/vqcpc.h``.
 """
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from itertools import chain
 from typing import Tuple
@@ -32,11 +33,10 @@ class ConfEncoder:
 
 
 class VQEmbeddingEMA(nn.Module):
-    """Buffer holder for the codebook (``model.py:89-101``).
-
-    ``encode`` / eval-mode ``forward`` (``model.py:103-155``) are served by the owning
-    ``Encoder`` (the VQ search is fused behind ``vqcpc_encoder_encode``); the EMA update of
-    training mode (``model.py:136-145``) is outside the inference path.
+    """Codebook buffers (``model.py:89-101``) + the reference's public ``encode`` / eval-mode ``forward``
+    (``model.py:103-155``) as thin wrappers over the owning ``Encoder``'s native handle (the same VQ kernel
+    ``Encoder.encode`` runs).  The EMA update of training mode (``model.py:136-145``) is outside the
+    inference path.
     """
 
     def __init__(self, n_embeddings, embedding_dim, commitment_cost=0.25, decay=0.999, epsilon=1e-5):
@@ -47,6 +47,52 @@ class VQEmbeddingEMA(nn.Module):
         self.register_buffer("embedding", embedding)
         self.register_buffer("ema_count", torch.zeros(n_embeddings))
         self.register_buffer("ema_weight", self.embedding.clone())
+        self._owner = None                              # weakref to the Encoder that holds the native handle
+
+    def __getstate__(self):                             # copy.deepcopy / pickle: the owner re-links itself
+        d = self.__dict__.copy()
+        d["_owner"] = None
+        return d
+
+    def _rows(self, x: Tensor):
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise RuntimeError("VQEmbeddingEMA: the MI355X path serves the codebook through its owning Encoder "
+                               "(construct it as Encoder(conf).codebook)")
+        _lib.require_cuda(x, "x")
+        _lib.require_same_device(x, self.embedding, "x")
+        D = self.embedding.size(1)
+        if x.dim() < 2 or x.size(-1) != D:
+            raise RuntimeError(f"expected x of shape (Batch, Time, {D}), got {tuple(x.shape)}")
+        xf = x.detach().to(torch.float32).reshape(-1, D).contiguous()
+        q = torch.empty_like(xf)
+        idx = torch.empty(xf.size(0), dtype=torch.int64, device=x.device)
+        h = owner._native()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().vqcpc_encoder_vq_encode(h, xf.data_ptr(), xf.size(0), q.data_ptr(), idx.data_ptr(),
+                                                           _lib.current_stream()))
+        return owner, h, xf, q, idx
+
+    @torch.no_grad()
+    def encode(self, x: Tensor):
+        """``model.py:103-115``: (quantized, indices (Batch, Time))."""
+        _, _, _, q, idx = self._rows(x)
+        return q.view_as(x), idx.view(x.size(0), x.size(1))
+
+    def forward(self, x: Tensor):
+        """``model.py:117-155`` in eval mode: (x + (q - x), 0.25 * mse, perplexity)."""
+        if self.training:
+            raise NotImplementedError("VQEmbeddingEMA: the EMA update of training mode (model.py:136-145) is outside "
+                                      "the inference path; call .eval()")
+        with torch.no_grad():
+            _, h, xf, q, idx = self._rows(x)
+            z_st = torch.empty_like(xf)
+            stats = torch.empty(2, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().vqcpc_encoder_forward_stats(h, xf.data_ptr(), q.data_ptr(), idx.data_ptr(), xf.size(0),
+                                                                   z_st.data_ptr(), stats[0:].data_ptr(), stats[1:].data_ptr(),
+                                                                   _lib.current_stream()))
+        return z_st.view_as(x), stats[0], stats[1]
 
 
 class Encoder(nn.Module):
@@ -61,6 +107,7 @@ class Encoder(nn.Module):
                                      *chain.from_iterable(block() for _ in range(4)),
                                      nn.Linear(conf.channels, conf.z_dim))
         self.codebook = VQEmbeddingEMA(conf.n_embeddings, conf.z_dim)
+        self.codebook._owner = weakref.ref(self)
         self.rnn = nn.LSTM(conf.z_dim, conf.c_dim, batch_first=True)
         self._handle = None
         self._handle_key = None
@@ -113,6 +160,23 @@ class Encoder(nn.Module):
             _lib.load().vqcpc_encoder_destroy(self._handle)
             self._handle = None
 
+    def __getstate__(self):                             # the native handle is per object: a copy builds its own
+        d = self.__dict__.copy()
+        d["_handle"], d["_handle_key"] = None, None
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.codebook._owner = weakref.ref(self)
+
+    def refresh(self):
+        """Drop the native handle so that the next call re-reads the parameters.  The handle holds re-laid
+        COPIES of the weights and is rebuilt automatically when a parameter's storage or ``_version`` changes
+        (``load_state_dict``, ``.to``, optimizer steps); a write through ``.data`` bumps neither -- call this
+        after one."""
+        self._release()
+        self._handle_key = None
+
     def __del__(self):
         try:
             self._release()
@@ -126,6 +190,7 @@ class Encoder(nn.Module):
             raise RuntimeError(f"expected mel of shape (B, {self.conf.in_channels}, T), got {tuple(mel.shape)}")
         if mel.size(2) < 2:
             raise RuntimeError("Conv1d(k=4, s=2, p=1) needs at least 2 mel frames")
+        _lib.require_same_device(mel, self.conv.weight, "mel")
         mel = mel.detach().to(torch.float32).contiguous()
         B, _, T = mel.shape
         To = (T - 2) // 2 + 1                        # nn.Conv1d(k4, s2, p1) output length (model.py:43)
@@ -159,6 +224,7 @@ class Encoder(nn.Module):
     def stage(self, mel: Tensor, stage: int, conv_mode: int = 0) -> Tensor:
         """Activations after one front-end stage (``vqcpc_encoder_stage``), rows (B, T/2, F)."""
         _lib.require_cuda(mel, "mel")
+        _lib.require_same_device(mel, self.conv.weight, "mel")
         mel = mel.detach().to(torch.float32).contiguous()
         B, _, T = mel.shape
         F = self.conf.z_dim if stage == 10 else self.conf.channels

@@ -144,6 +144,17 @@ class Vocoder(nn.Module):
         except Exception:
             pass
 
+    def __getstate__(self):                             # the native handle is per object: a copy builds its own
+        d = self.__dict__.copy()
+        d["_handle"], d["_handle_key"] = None, None
+        return d
+
+    def refresh(self):
+        """Drop the native handle (re-laid COPIES of the weights) so the next call re-reads the parameters: needed
+        after an in-place write through ``.data``, which changes neither a parameter's storage nor its ``_version``."""
+        self._release()
+        self._handle_key = None
+
     def set_option(self, name: str, value: int):
         """Decode-loop options of ``vqcpc_vocoder_set_option`` (``use_graph``, ``steps_per_graph``)."""
         _lib.check(_lib.load().vqcpc_vocoder_set_option(self._native(), name.encode(), int(value)))
@@ -156,14 +167,15 @@ class Vocoder(nn.Module):
         return ms.value, n.value
 
     def kernel_times(self, reps: int = 1000):
-        """(us GRU step, us fc1, us fc2 + draw, decode slots per launch): ``vqcpc_vocoder_kernel_times``."""
-        out = (C.c_float * 4)()
+        """(us GRU step, us fc1, us fc2 + draw, decode slots per launch, GRU kernel kind): ``vqcpc_vocoder_kernel_times``."""
+        out = (C.c_float * 5)()
         _lib.check(_lib.load().vqcpc_vocoder_kernel_times(self._native(), int(reps), out, _lib.current_stream()))
         return tuple(float(v) for v in out)
 
     # ------------------------------------------------------------------ reference surface
     def _prep(self, z: Tensor, speaker: Tensor):
         _lib.require_cuda(z, "z")
+        _lib.require_same_device(z, self.code_embedding.weight, "z")
         if z.dim() != 2 or speaker.dim() != 1 or speaker.size(0) != z.size(0):
             raise RuntimeError(f"expected z (B, T') and speaker (B), got {tuple(z.shape)} and {tuple(speaker.shape)}")
         if z.is_floating_point() or speaker.is_floating_point():
