@@ -219,3 +219,103 @@ def test_default_paths_at_many_batch_sizes_equal_single_utterance_calls():
             L = 320 * n_codes[i]
             assert torch.equal(m[i, :L], one[0, :L]), (B, i)
             assert not m[i, L:].any(), (B, i)
+
+
+def _check_rows_direct(voc, sd, B, rows, steps, seed, utt0, tag):
+    """The decode kernels a batch of B takes, checked DIRECTLY against the oracles (not via single-utterance HIP
+    calls): the C oracle draw by draw on `rows` (5 ms per step, so a spread-out subset: first / last column of every
+    tile), and the torch-CPU port teacher-forced on ALL rows (its logits are within 2e-5 of the C oracle's, so the
+    tie window is 4e-5 there)."""
+    from oracle import torch_ref
+    z = synth.randint(f"{tag}/z", (B, 2), 512)
+    spk = torch.arange(B) * 5 % 102
+    wav, mu = voc.generate(z.cuda(), spk.cuda(), seed=seed, utt_base=utt0, return_mulaw=True, max_steps=steps)
+    wav, mu = wav.cpu().numpy(), mu.cpu().numpy()
+    assert np.isfinite(wav).all() and not mu[:, steps:].any()
+    n_exact = 0
+    for b in rows:
+        s_gpu = mu[b, :steps]
+        inputs = np.concatenate([[128], s_gpu[:-1]])
+        r = oracle.vocoder_generate(sd, z[b].numpy(), int(spk[b]), seed=seed, utterance=utt0 + b, n_steps=steps,
+                                    inputs=inputs, want_logits=True)
+        n_exact += int((r["samples"] == s_gpu).sum())
+        for t in np.nonzero(r["samples"] != s_gpu)[0]:
+            pick, sc = oracle.sample_from_logits(r["logits"][t], seed, utt0 + b, int(t))
+            assert sc[pick] - sc[int(s_gpu[t])] <= 2e-5, (tag, b, int(t))
+        assert np.array_equal(wav[b, :steps], np.array([oracle.mulaw_decode(int(s)) for s in s_gpu], np.float32))
+    assert n_exact >= 0.999 * steps * len(rows)
+    tv = torch_ref.TorchVocoder(sd)
+    x_in = torch.from_numpy(np.concatenate([np.full((B, 1), 128), mu[:, : steps - 1]], axis=1))
+    noise = torch_ref.make_noise(B, steps, seed, utt0)
+    _, _, lg = tv.generate(z, spk, seed=seed, utt_base=utt0, n_steps=steps, inputs=x_in, want_logits=True, noise=noise)
+    sc = (lg + noise).numpy()
+    got = np.take_along_axis(sc, mu[:, :steps, None], axis=2)[..., 0]
+    assert float((sc.max(axis=2) - got).max()) <= 4e-5, tag
+    return n_exact
+
+
+def test_bench_kernel_32_utterances_direct_oracle():
+    """The kernel bench.py's default workload runs -- ar_gru_kernel<14,2,.> with two full tiles, fc1 in 8-row groups --
+    at 32 utterances x 480 samples, against the oracles directly."""
+    voc, sd = vocoder()
+    _check_rows_direct(voc, sd, 32, [0, 15, 16, 31, 7, 24], 480, seed=13, utt0=0, tag="d32")
+    assert voc.kernel_times(20)[4] == 1.0              # kernel kind of the call above: two tiles per workgroup
+
+
+def test_large_batch_kernel_96_utterances_direct_oracle():
+    """ar_gru_big_kernel (6 tiles: LDS-staged state, full 16-row gate tiles) against the oracles directly."""
+    voc, sd = vocoder()
+    _check_rows_direct(voc, sd, 96, [0, 17, 47, 64, 95], 480, seed=5, utt0=200, tag="d96")
+    assert voc.kernel_times(20)[4] == 2.0
+
+
+def test_two_tile_groups_48_utterances_direct_oracle():
+    """48 utterances = 3 tiles = a 2-tile and a 1-tile group on two streams (fragments requested 6 ahead), against
+    the oracles directly; rows from both groups."""
+    voc, sd = vocoder()
+    _check_rows_direct(voc, sd, 48, [0, 31, 32, 47, 20], 480, seed=99, utt0=1000, tag="d48")
+
+
+def test_configs3_shard_full_size_properties():
+    """BASELINE configs[3]'s per-GPU shard at full size (32 utterances x 32 000 samples, the bench workload):
+    finite, in range, non-degenerate, and three rows equal to single-utterance calls with the same stream ids."""
+    voc, _ = vocoder()
+    z = synth.randint("c4/z", (32, 100), 512).cuda()
+    spk = (torch.arange(32) % 102).cuda()
+    wav, mu = voc.generate(z, spk, seed=13, utt_base=0, return_mulaw=True)
+    assert wav.shape == (32, 32000) and torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+    assert int(mu.min()) >= 0 and int(mu.max()) <= 255
+    assert all(mu[b].unique().numel() > 32 for b in range(32))
+    for b in (0, 17, 31):
+        one = voc.generate(z[b:b + 1], spk[b:b + 1], seed=13, utt_base=b, return_mulaw=True)[1]
+        assert torch.equal(one[0], mu[b]), b
+
+
+def test_teacher_forced_scan_chunks_and_training_shape():
+    """Vocoder.forward as a fused scan: GRU steps only, fc1 / fc2 as chunked GEMMs.  Chunk sizes that
+    split Ts differently (one replay per chunk: 160 steps, last chunk partial) give the same bits; a batch that takes
+    the large-batch GRU kernel agrees with the two-tile kernel's rows; all within 2e-5 of the oracle."""
+    voc, sd = vocoder()
+    B, Tc, Ts = 3, 3, 700
+    z = synth.randint("tf2/z", (B, Tc), 512)
+    spk = synth.randint("tf2/spk", (B,), 102)
+    x = synth.randint("tf2/x", (B, Ts), 256)
+    a = voc(x.cuda(), z.cuda(), spk.cuda())
+    try:
+        voc.set_option("tf_chunk_replays", 1)
+        b = voc(x.cuda(), z.cuda(), spk.cuda())
+        voc.set_option("use_graph", 0)
+        c = voc(x.cuda(), z.cuda(), spk.cuda())
+    finally:
+        voc.set_option("use_graph", 1)
+        voc.set_option("tf_chunk_replays", 4)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    r = oracle.vocoder_generate(sd, z[1].numpy(), int(spk[1]), seed=0, n_steps=Ts, inputs=x[1].numpy(), want_logits=True)
+    assert float(np.abs(a[1].cpu().numpy() - r["logits"]).max()) <= 2e-5
+    # 100 utterances (7 tiles -> large-batch kernel), short: rows 0..2 are the same utterances as above
+    B2 = 100
+    z2 = torch.cat([z, synth.randint("tf2/z2", (B2 - B, Tc), 512)])
+    spk2 = torch.cat([spk, synth.randint("tf2/spk2", (B2 - B,), 102)])
+    x2 = torch.cat([x[:, :200], synth.randint("tf2/x2", (B2 - B, 200), 256)])
+    d = voc(x2.cuda(), z2.cuda(), spk2.cuda())
+    assert d.shape == (B2, 200, 256) and torch.equal(d[:B], a[:, :200])

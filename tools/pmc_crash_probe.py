@@ -56,7 +56,7 @@ if mode == "eager":
 steps = int(os.environ.get("PROBE_STEPS_PER_GRAPH", "0"))
 if steps:
     voc.set_option("steps_per_graph", steps)
-z = synth.randint("probe/z", (32, 2), 512).cuda()
+z = synth.randint("probe/z", (32, int(os.environ.get("PROBE_CODES", "2"))), 512).cuda()
 spk = (torch.arange(32) % 102).cuda()
 print(f"[probe] pid {os.getpid()} mode {mode}: generate()", file=sys.stderr, flush=True)
 wav = voc.generate(z, spk, seed=13, utt_base=0)

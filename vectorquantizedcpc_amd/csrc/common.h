@@ -55,6 +55,11 @@ struct DevBuf {
 int vq_gemm_chain(const float *A, int lda, const float *W, const float *bias, float *Y, int ldy,
                   int M, int N, int K, int KC, hipStream_t s);
 
+// The same with an epilogue: optional ReLU, and an optional output row map for chunked scans -- row m is stored at
+// (m / ydiv) * ystride + yoff + m % ydiv, or not at all when yoff + m % ydiv >= ylim (ydiv == 0: plain row m).
+int vq_gemm_chain_ex(const float *A, int lda, const float *W, const float *bias, float *Y, int ldy,
+                     int M, int N, int K, int KC, int relu, int ydiv, int ystride, int yoff, int ylim, hipStream_t s);
+
 // ---- recurrent machinery (vocoder.hip), shared with the encoder's LSTM.
 struct LstmPlan;   // opaque, owns fragment-ordered weights
 int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,

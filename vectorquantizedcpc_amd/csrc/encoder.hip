@@ -70,6 +70,9 @@ struct GemmP {
     int M, N, K, KC;
     // im2col source (AMODE 1/2): mel (B, C, T)
     const float *x; int C, T, To;
+    // epilogue extras (vq_gemm_chain_ex): ReLU; output row m -> (m / ydiv) * ystride + yoff + m % ydiv, rows whose
+    // yoff + m % ydiv >= ylim are not stored (ydiv == 0: row m)
+    int relu, ydiv, ystride, yoff, ylim;
 };
 
 template <int AMODE>
@@ -115,7 +118,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, const f32x16 &tot,
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < p.M) p.Y[(size_t)m * p.ldy + col] = tot[r];
+        if (m >= p.M) continue;
+        size_t row = (size_t)m;
+        if (p.ydiv > 0) {
+            const int q = m / p.ydiv, t = p.yoff + (m - q * p.ydiv);
+            if (t >= p.ylim) continue;
+            row = (size_t)q * p.ystride + t;
+        }
+        const float v = tot[r];
+        p.Y[row * p.ldy + col] = (p.relu && v < 0.f) ? 0.f : v;
     }
 }
 
@@ -237,6 +248,17 @@ int vq_gemm_chain(const float *A, int lda, const float *W, const float *bias, fl
     GemmP p{};
     p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.Y = Y; p.ldy = ldy;
     p.M = M; p.N = N; p.K = K; p.KC = KC;
+    return launch_gemm<0>(p, s);
+}
+
+int vq_gemm_chain_ex(const float *A, int lda, const float *W, const float *bias, float *Y, int ldy,
+                     int M, int N, int K, int KC, int relu, int ydiv, int ystride, int yoff, int ylim, hipStream_t s) {
+    VQ_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+               "gemm_chain: operands must be 16-byte aligned");
+    GemmP p{};
+    p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.Y = Y; p.ldy = ldy;
+    p.M = M; p.N = N; p.K = K; p.KC = KC;
+    p.relu = relu; p.ydiv = ydiv; p.ystride = ystride; p.yoff = yoff; p.ylim = ylim;
     return launch_gemm<0>(p, s);
 }
 

@@ -65,6 +65,35 @@ static int build_wfrag(const float *W, int ldw, int n_rg, int K, int ksplit, int
     return VQCPC_OK;
 }
 
+// Packed GRU fragments: the 12 gate rows of a 4-unit row group WITHOUT the 4 padding rows of the 16-row MFMA
+// tile.  Per (rg, K quarter w, super-step s): 48 float4 = [kq 0..3][i 0..11], 768 B = six whole 128-B lines;
+//   Wp[(((rg*4 + w)*SW + s)*48 + kq*12 + i] = W[(i>>2)*H + 4*rg + (i&3)][16*(w*SW + s) + 4*kq + 0..3]
+// A lane of a padding row (i >= 12) re-reads row 0 of its kq group (an address a live lane also loads, so it
+// costs no traffic); its MFMA output rows are never read.  The padded layout streams 12.8 MB for 9.6 MB of W_hh
+// and masking lanes does not help (the holes are 64 B inside 128-B lines): VERDICT r1 item 4.
+__global__ void build_wfrag12_kernel(const float *__restrict__ W, int ldw, float *__restrict__ Wp, int n_rg, int K, int H) {
+    const int SW = K / 64;
+    const size_t total = (size_t)n_rg * 4 * SW * 48;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int e = (int)(id % 48);
+    size_t r = id / 48;
+    const int s = (int)(r % SW); r /= SW;
+    const int w = (int)(r % 4);
+    const int rg = (int)(r / 4);
+    const int kq = e / 12, i = e % 12;
+    const int row = (i >> 2) * H + 4 * rg + (i & 3);
+    ((float4 *)Wp)[id] = *(const float4 *)(W + (size_t)row * ldw + 16 * (w * SW + s) + 4 * kq);
+}
+static int build_wfrag12(const float *W, int ldw, int n_rg, int K, int H, float **out) {
+    VQ_REQUIRE(K % 64 == 0 && ldw % 4 == 0, "build_wfrag12: K=%d not a multiple of 64", K);
+    const size_t n4 = (size_t)n_rg * (K / 16) * 48;
+    HIP_TRY(hipMalloc((void **)out, n4 * sizeof(float4)));
+    hipLaunchKernelGGL(build_wfrag12_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, W, ldw, *out, n_rg, K, H);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
 template <int SW>
 __device__ __forceinline__ void load_wfrag(const float *Wf, int rg, int ksplit, int wave, int lane, float4 (&wf)[SW]) {
     const float4 *p = (const float4 *)Wf + ((size_t)(rg * ksplit + wave) * SW) * 64 + lane;
@@ -266,6 +295,10 @@ struct ArCall {
     int F, Ts, Lout, max_t, nbt;
     unsigned long long seed;
     int t_base;                // advanced on device after every graph replay
+    // teacher-forced scan (Vocoder.forward): only the GRU step runs per sample; h_t of every step of the current
+    // chunk is kept, row-major, for the two batched GEMMs (fc1 + ReLU, fc2) that follow the chunk
+    float *hall;               // [B][CH][Hr] or null
+    int CH, hall_t0;           // chunk length (a multiple of S); first step of the chunk in flight (advanced on device)
 };
 
 // Timeline stamps of workgroup (0, 0) (100 MHz wall clock) for tools/decode_timeline.py: compiled in only
@@ -282,7 +315,8 @@ extern "C" int vqcpc_debug_ar_stamps(unsigned long long *out) {
 #endif
 
 struct ArModel {               // constant per handle (baked into the captured graph)
-    const float *Wf_hh, *b_hh, *Gemb;
+    const float *b_hh, *Gemb;
+    const float *Wf_hh12;      // W_hh in packed 12-row groups (ar_gru_kernel: no padding rows streamed)
     const float *Wf_hh16;      // W_hh in gate-major 16-row tiles (large-batch kernel: no padding rows)
     float *gcur;               // [Sp][3Hr] the Gcond row every slot uses during the replay in flight (gc_replay)
     int gc_replay;             // 1: upsample % steps_per_graph == 0, so a slot stays on one conditioning frame per replay
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
         size_t hi = 0;
         int xraw = 0;
         bool emit = false;
-        float *wavp = nullptr;
+        float *wavp = nullptr, *hallp = nullptr;
         int64_t *mulp = nullptr;
         if (mfma_wave) {
             // Fragments are requested LEADP super-steps ahead of their MFMAs, not all at once.  Measured
@@ -387,7 +421,8 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             // streams want more in flight).  launch_ar_steps picks 6 for that case, 3 otherwise.
             constexpr int LEAD = SW < LEADP ? SW : LEADP;
             float4 wf[SW], hv[NB][SW];
-            const float4 *wp = (const float4 *)m.Wf_hh + ((size_t)(rg * 4 + kw) * SW) * 64 + lane;
+            const float4 *wp = (const float4 *)m.Wf_hh12 + ((size_t)(rg * 4 + kw) * SW) * 48 + (lane >> 4) * 12 +
+                               ((lane & 15) < 12 ? (lane & 15) : 0);          // packed rows; padding lanes alias row 0
             const float4 *hp[NB];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
@@ -398,7 +433,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             }
 #pragma unroll
             for (int s = 0; s < LEAD; ++s) {
-                wf[s] = wp[s * 64];
+                wf[s] = wp[s * 48];
 #pragma unroll
                 for (int q = 0; q < NB; ++q) hv[q][s] = hp[q][s * 64];
             }
@@ -409,7 +444,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 if (s + LEAD < SW) {
-                    wf[s + LEAD] = wp[(s + LEAD) * 64];
+                    wf[s + LEAD] = wp[(s + LEAD) * 48];
 #pragma unroll
                     for (int q = 0; q < NB; ++q) hv[q][s + LEAD] = hp[q][(s + LEAD) * 64];
                 }
@@ -474,6 +509,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
                     gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
                 }
                 hold = first ? 0.f : hprev;                     // a new utterance starts from h = 0
+                if (c.hall) hallp = c.hall + ((size_t)sl.row * c.CH + (lt - c.hall_t0)) * Hr + unit;
             }
             if (rg == 0 && wave == 0) ((float4 *)mt)[lane] = mtl;
             AR_STAMP(tid == 0, 0, 2);
@@ -492,7 +528,9 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             const float r = sigmoidf_((ge0 + gc0) + (gr + bh0));
             const float z = sigmoidf_((ge1 + gc1) + (gz + bh1));
             const float n = tanhf((ge2 + gc2) + r * (gn + bh2));
-            hout[hi] = (1.0f - z) * n + z * hold;
+            const float hn = (1.0f - z) * n + z * hold;
+            hout[hi] = hn;
+            if (hallp) *hallp = hn;
         }
         AR_STAMP(tid == 0, 0, 3);
     }
@@ -547,6 +585,7 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
         const int sg = (gbt < nbt ? gbt : nbt - 1) * 16 + b;
         float ge[2][3] = {}, gc[2][3], bh[2][3], hold[2] = {0.f, 0.f}, hprev[2];
         size_t hi[2];
+        float *hallp = nullptr;
         // first level of the operand chain: everything with a fixed address (as in ar_gru_kernel)
         Cand16 cd;
         load_candidates16(m, sg, cd);
@@ -592,6 +631,7 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
                 }
                 hold[p] = first ? 0.f : hprev[p];
             }
+            if (c.hall) hallp = c.hall + ((size_t)sl.row * c.CH + (lt - c.hall_t0)) * Hr + 16 * blk + 8 * uh + u;
         }
         big_stage_store(hs, t4, tid, st);
         __syncthreads();
@@ -609,7 +649,9 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
                 const float rr = sigmoidf_((ge[p][0] + gc[p][0]) + (gr + bh[p][0]));
                 const float z = sigmoidf_((ge[p][1] + gc[p][1]) + (gz + bh[p][1]));
                 const float n = tanhf((ge[p][2] + gc[p][2]) + rr * (gn + bh[p][2]));
-                hout[hi[p]] = (1.0f - z) * n + z * hold[p];
+                const float hn = (1.0f - z) * n + z * hold[p];
+                hout[hi[p]] = hn;
+                if (hallp) hallp[4 * p] = hn;
             }
         }
     } else {
@@ -738,7 +780,10 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     AR_STAMP(tid == 0, 2, 3);
 }
 
-__global__ void ar_advance_kernel(ArCall *c, int n) { c->t_base += n; }
+__global__ void ar_advance_kernel(ArCall *c, int n) {
+    c->t_base += n;
+    if (c->hall && c->t_base - c->hall_t0 >= c->CH) c->hall_t0 += c->CH;      // next chunk of the teacher-forced scan
+}
 // Between replays (and once before the first): the slot row of the replay that starts at t_base, and -- when a
 // slot stays on one conditioning frame per replay (gc_replay) -- that frame's Gcond row per slot.
 // One workgroup per decode slot.
@@ -823,7 +868,8 @@ struct vqcpc_vocoder {
     float *code_emb = nullptr, *spk_emb = nullptr;
     float *p_wih[2] = {}, *p_bih[2] = {}, *p_bhh[2] = {}, *p_wf[2] = {};   // per layer, both directions stacked
     float *w_cond = nullptr, *b_ih = nullptr, *Gemb = nullptr;
-    float *Wf_hh = nullptr, *Wf_hh16 = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *Wf_fc1h = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
+    float *Wf_hh12 = nullptr, *Wf_hh16 = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *Wf_fc1h = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
+    float *w_fc1 = nullptr, *w_fc2 = nullptr;      // plain (rows, K) copies for the teacher-forced scan's batched GEMMs
     float *mulaw_tab = nullptr;
     // A decode call runs as 1 or 2 independent TILE GROUPS (disjoint utterance tiles, own state,
     // own call record, own captured graph).  Two groups run on two streams so that one group's GRU
@@ -838,6 +884,8 @@ struct vqcpc_vocoder {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf series, gi, out0, cond, gcond, hseq, len;
+    DevBuf hall, a1c;                    // teacher-forced scan: h_t and fc1 outputs of one chunk
+    int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
     int big_min_tiles = 6;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never)
@@ -868,10 +916,10 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->ev_fork) (void)hipEventDestroy(v->ev_fork);
     if (v->ev_join) (void)hipEventDestroy(v->ev_join);
     float *ptrs[] = {v->code_emb, v->spk_emb, v->p_wih[0], v->p_wih[1], v->p_bih[0], v->p_bih[1], v->p_bhh[0],
-                     v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh, v->Wf_hh16, v->b_hh,
-                     v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab};
+                     v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh12, v->Wf_hh16, v->b_hh,
+                     v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab, v->w_fc1, v->w_fc2};
     for (float *p : ptrs) if (p) (void)hipFree(p);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -916,11 +964,13 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     float *emb = nullptr;
     TRY(dcopy(&emb, w->ar_embedding, (size_t)w->n_cls * de));
     TRY(vq_gemm_chain(emb, de, w_emb, nullptr, v->Gemb, 3 * Hr, w->n_cls, 3 * Hr, de, de, 0));
-    TRY(build_wfrag(w->ar_w_hh, Hr, Hr / 4, Hr, 4, 3, Hr, &v->Wf_hh));
+    TRY(build_wfrag12(w->ar_w_hh, Hr, Hr / 4, Hr, Hr, &v->Wf_hh12));
     if (Hr % 16 == 0) TRY(build_wfrag(w->ar_w_hh, Hr, 3 * (Hr / 16), Hr, 4, 16, Hr, &v->Wf_hh16));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 16, Hr, 4, 0, 0, &v->Wf_fc1));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 8, Hr, 4, 8, 0, &v->Wf_fc1h));
     TRY(build_wfrag(w->fc2_weight, w->Hf, w->n_cls / 16, w->Hf, 1, 0, 0, &v->Wf_fc2));
+    TRY(dcopy(&v->w_fc1, w->fc1_weight, (size_t)w->Hf * Hr));
+    TRY(dcopy(&v->w_fc2, w->fc2_weight, (size_t)w->n_cls * w->Hf));
     TRY(dcopy(&v->b_fc1, w->fc1_bias, w->Hf));
     TRY(dcopy(&v->b_fc2, w->fc2_bias, w->n_cls));
     // mu-law decode table (preprocess.py:30-35, evaluated in float64 like the reference's numpy)
@@ -984,6 +1034,11 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         return VQCPC_OK;
     }
     if (!strcmp(name, "two_groups")) { v->two_groups = value != 0; return VQCPC_OK; }
+    if (!strcmp(name, "tf_chunk_replays")) {
+        VQ_REQUIRE(value >= 1 && value <= 64, "tf_chunk_replays must be in [1, 64]");
+        v->tf_chunk_replays = value;
+        return VQCPC_OK;
+    }
     if (!strcmp(name, "slots")) {
         VQ_REQUIRE(value >= 0 && value <= 65536, "slots out of range");
         v->n_slots = value;
@@ -1030,7 +1085,9 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     return VQCPC_OK;
 }
 
-static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int nbt, int n, hipStream_t s) {
+// tf: teacher-forced scan -- x_{t-1} comes from the inputs, so only the GRU step runs per sample (fc1 / fc2 follow
+// as batched GEMMs over the whole chunk, run_ar)
+static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int nbt, int n, bool tf, hipStream_t s) {
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
     // large-batch GRU kernel: >= big_min_tiles tiles in flight, Hr a multiple of 16, LDS fits
@@ -1052,6 +1109,7 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
             else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt); \
             else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
             else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
+            if (tf) break; \
             if (nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
             else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
             break;
@@ -1059,12 +1117,24 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
 #undef CASE
             default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
         }
-        hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
+        if (!tf) hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
     }
-    hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
+    if (!tf) hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, call, n);
     hipLaunchKernelGGL(ar_next_row_kernel, dim3(nbt * 16), dim3(256), 0, s, m, (const ArCall *)call);
     HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+// Teacher-forced scan, after chunk `chunk` (steps [chunk*CH, (chunk+1)*CH)) has left its h_t in v->hall:
+// a = relu(W1 h + b1) for all B*CH rows, logits = W2 a + b2 stored at (b, chunk*CH + tt) for tt < Ts - chunk*CH.
+static int tf_chunk_gemms(vqcpc_vocoder *v, int B, int Ts, int CH, int chunk, float *logits, hipStream_t s) {
+    const auto &d = v->d;
+    const int M = B * CH;
+    TRY(vq_gemm_chain_ex(v->hall.as<float>(), d.Hr, v->w_fc1, v->b_fc1, v->a1c.as<float>(), d.Hf, M, d.Hf, d.Hr, d.Hr,
+                         1, 0, 0, 0, 0, s));
+    TRY(vq_gemm_chain_ex(v->a1c.as<float>(), d.Hf, v->w_fc2, v->b_fc2, logits, d.n_cls, M, d.n_cls, d.Hf, d.Hf,
+                         0, CH, Ts, chunk * CH, Ts, s));
     return VQCPC_OK;
 }
 
@@ -1117,7 +1187,8 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // Tile groups: 3..big_min_tiles-1 tiles, or >= 2*big_min_tiles (both halves on the large-batch kernel), split in two.  (Measured: 2 x 16 utterances is slower than one
     // group of 32 -- the chip retires only ~0.43 dependent launches per us across queues -- while
     // 2 x 32 runs at 14.5 us per sample against 17.3 us for one group of 64.)
-    const bool split = v->two_groups && v->use_graph && nbt >= 3 &&
+    const bool tf = inputs != nullptr;     // teacher-forced scan: one group, GRU steps only, chunked GEMMs for fc1 / fc2
+    const bool split = !tf && v->two_groups && v->use_graph && nbt >= 3 &&
                        !(v->big_min_tiles > 0 && nbt >= v->big_min_tiles && nbt < 2 * v->big_min_tiles);
     const int n_grp = split ? 2 : 1;
     const int tiles[2] = {split ? (nbt + 1) / 2 : nbt, split ? nbt / 2 : 0};
@@ -1172,10 +1243,17 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
         c.slots = G.slot_tab.as<ArSlot>(); c.S = S; c.Sp = Spg; c.n_rep = rep[g] > 0 ? rep[g] : 1;
         c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = gmax[g]; c.nbt = nb; c.seed = seed; c.t_base = 0;
+        if (tf) {
+            c.CH = v->tf_chunk_replays * S;
+            TRY(v->hall.reserve((size_t)B * c.CH * Hr * sizeof(float)));
+            TRY(v->a1c.reserve((size_t)B * c.CH * d.Hf * sizeof(float)));
+            c.hall = v->hall.as<float>(); c.hall_t0 = 0;
+            c.logits = nullptr;                       // written by the chunk GEMMs, not by ar_fc2_kernel
+        }
         HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
         ArModel &m = models[g];
         m = ArModel{};
-        m.Wf_hh = v->Wf_hh; m.Wf_hh16 = v->Wf_hh16; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
+        m.Wf_hh12 = v->Wf_hh12; m.Wf_hh16 = v->Wf_hh16; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
         m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
         m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>(); m.cur = G.cur.as<ArSlot>(); m.gcur = G.gcur.as<float>();
         m.gc_replay = d.upsample_t % S == 0;
@@ -1202,18 +1280,22 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
                 G.graphs.clear();
                 memcpy(G.baked, now, sizeof now);
             }
-            const int gkey = (tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6;     // the captured ArModel bakes all three
+            const int gkey = ((tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6) * 2 + (tf ? 1 : 0);   // what the capture bakes
             auto it = G.graphs.find(gkey);
             if (it == G.graphs.end()) {
                 hipGraph_t gr = nullptr;
                 hipGraphExec_t ge = nullptr;
                 HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
-                int rc = launch_ar_steps(v, models[g], G.call, tiles[g], S, v->cap_stream);
-                hipError_t e = hipStreamEndCapture(v->cap_stream, &gr);
-                if (rc != VQCPC_OK) return rc;
+                int rc = launch_ar_steps(v, models[g], G.call, tiles[g], S, tf, v->cap_stream);
+                hipError_t e = hipStreamEndCapture(v->cap_stream, &gr);     // always end the capture, also on failure
+                if (rc != VQCPC_OK || e != hipSuccess) {
+                    if (gr) (void)hipGraphDestroy(gr);
+                    if (rc != VQCPC_OK) return rc;
+                    HIP_TRY(e);
+                }
+                e = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(gr);
                 HIP_TRY(e);
-                HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
-                HIP_TRY(hipGraphDestroy(gr));
                 it = G.graphs.emplace(gkey, ge).first;
             }
             exec[g] = it->second;
@@ -1227,13 +1309,19 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         for (int r = 0; r < nr; ++r) {
             if (r < rep[0]) HIP_TRY(hipGraphLaunch(exec[0], s));
             if (n_grp == 2 && r < rep[1]) HIP_TRY(hipGraphLaunch(exec[1], v->side_stream));
+            if (tf && ((r + 1) % v->tf_chunk_replays == 0 || r + 1 == nr))
+                TRY(tf_chunk_gemms(v, B, Ts, calls[0].CH, r / v->tf_chunk_replays, logits, s));
         }
         if (n_grp == 2) {
             HIP_TRY(hipEventRecord(v->ev_join, v->side_stream));
             HIP_TRY(hipStreamWaitEvent(s, v->ev_join, 0));
         }
     } else {
-        for (int t0 = 0; t0 < max_t; t0 += S) TRY(launch_ar_steps(v, models[0], v->grp[0].call, nbt, S, s));
+        for (int t0 = 0, r = 0; t0 < max_t; t0 += S, ++r) {
+            TRY(launch_ar_steps(v, models[0], v->grp[0].call, nbt, S, tf, s));
+            if (tf && ((r + 1) % v->tf_chunk_replays == 0 || t0 + S >= max_t))
+                TRY(tf_chunk_gemms(v, B, Ts, calls[0].CH, r / v->tf_chunk_replays, logits, s));
+        }
     }
     HIP_TRY(hipEventRecord(v->ev1, s));
     v->last_steps = max_t;
