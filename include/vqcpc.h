@@ -96,6 +96,11 @@ void vqcpc_encoder_destroy(vqcpc_encoder *enc);
 int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
                          float *z_q, float *c, int64_t *idx, float *z_pre, void *stream);
 
+/* Encoder options.  fused: -1 (default) = the one-launch fused front end (conv, LayerNorms, FC stack and VQ search for 16
+ * rows per workgroup, activations resident in LDS) whenever the layout supports it (4 * in_channels <= 512), 0 = the
+ * layered kernels (one launch per module of model.py:43-55), 1 = fused or error.  Both paths produce the same bits. */
+int vqcpc_encoder_set_option(vqcpc_encoder *enc, const char *name, int value);
+
 /* Activations after one stage of the front end for the same inputs as encode() -- the analogue
  * of a forward hook on the reference's modules (encode.py:34-40 hooks encoder.encoder[-1]):
  * stage 0 = conv output transposed to rows (model.py:65-67), 1 = encoder.0+1 (LN, ReLU),

@@ -157,3 +157,53 @@ def test_full_size_properties():
         zb, _, ib = enc.encode(mel[b:b + 1], conv_mode=2)
         assert torch.equal(ib[0], i1[b]) and torch.equal(zb[0], z1[b])
     assert torch.equal(enc.encode_indices(mel), i1)
+
+
+@pytest.mark.parametrize("name", ["c2_init", "odd_2x33", "c1_init", "c2_random_data"])
+def test_layered_and_fused_front_ends_same_bits(name, golden_dir):
+    """The one-launch fused front end (default) and the layered kernels (one launch per module) are two schedules of the
+    same rounding sequence: every stage, z and the indices carry the same bits, and both equal the reference's SHAs."""
+    g, enc, sd, mel = load_case(name, golden_dir)
+    melc = mel.cuda()
+    outs = {}
+    try:
+        for fused in (1, 0):
+            enc.set_option("fused", fused)
+            z, c, idx = enc.encode(melc)
+            stages = [enc.stage(melc, s) for s in range(11)]
+            outs[fused] = (z, idx, stages)
+    finally:
+        enc.set_option("fused", -1)
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    for s in range(11):
+        assert torch.equal(outs[0][2][s].view(torch.int32), outs[1][2][s].view(torch.int32)), s
+    assert sha(outs[1][0].cpu().numpy()) == str(g["sha_z"])
+    assert sha(outs[1][2][10].cpu().numpy()) == str(g["sha_z_pre"])
+    assert sha(outs[1][2][0].cpu().numpy()) == str(g["sha_conv"])
+
+
+def test_vq_embedding_encode_and_forward_standalone(golden_dir):
+    """VQEmbeddingEMA.encode / eval forward called on their own (model.py:103-155) equal what Encoder.encode /
+    Encoder.forward compute from the same pre-VQ rows."""
+    g, enc, sd, mel = load_case("c2_init", golden_dir)
+    melc = mel.cuda()
+    z, _, idx = enc.encode(melc)
+    z_pre = enc.stage(melc, 10)
+    q, i2 = enc.codebook.encode(z_pre)
+    assert torch.equal(i2, idx) and torch.equal(q, z) and i2.shape == idx.shape
+    zf, _, loss, ppl = enc(melc)
+    q2, loss2, ppl2 = enc.codebook(z_pre)
+    assert torch.equal(q2, zf) and float(loss2) == float(loss) and float(ppl2) == float(ppl)
+    with pytest.raises(RuntimeError):
+        enc.codebook.encode(z_pre.cpu())
+    w = enc.encoder[2].weight
+    w.data.mul_(2.0)                                   # a write through .data bumps no version: refresh() re-reads
+    try:
+        assert torch.equal(enc.encode(melc)[2], idx)
+        enc.refresh()
+        assert not torch.equal(enc.encode(melc)[2], idx)
+    finally:
+        w.data.mul_(0.5)
+        enc.refresh()
+    assert torch.equal(enc.encode(melc)[2], idx)

@@ -59,6 +59,20 @@ if steps:
 z = synth.randint("probe/z", (32, int(os.environ.get("PROBE_CODES", "2"))), 512).cuda()
 spk = (torch.arange(32) % 102).cuda()
 print(f"[probe] pid {os.getpid()} mode {mode}: generate()", file=sys.stderr, flush=True)
+if os.environ.get("PROBE_BENCH_SEQUENCE"):
+    # what round 1's crashing command did: bench.py --steps 1 --warmup 1 = (encoder + generate) twice on cached graphs,
+    # then 3 x 2020 back-to-back launches of the timing harness
+    enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
+    enc.load_state_dict(synth.encoder_state_dict())
+    enc = enc.cuda().eval()
+    mel = synth.mel("probe/mel", 32, 2 * z.shape[1]).cuda()
+    for it in range(2):
+        idx = enc.encode_indices(mel)
+        wav = voc.generate(idx, spk, seed=13, utt_base=0)
+        print(f"[probe] bench sequence: call {it} enqueued", file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    print("[probe] bench sequence: both calls finished; timing harness", file=sys.stderr, flush=True)
+    print("[probe] kernel_times", voc.kernel_times(2000), file=sys.stderr, flush=True)
 wav = voc.generate(z, spk, seed=13, utt_base=0)
 torch.cuda.synchronize()
 print(f"[probe] mode {mode} finished, |wav| max {float(wav.abs().max()):.3f}", file=sys.stderr, flush=True)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvqcpc_hip.so")
 SYMBOLS = [
     "vqcpc_abi_version", "vqcpc_last_error", "vqcpc_device_count",
     "vqcpc_encoder_create", "vqcpc_encoder_destroy", "vqcpc_encoder_encode",
-    "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage", "vqcpc_encoder_vq_encode",
+    "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage", "vqcpc_encoder_vq_encode", "vqcpc_encoder_set_option",
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
@@ -69,6 +69,7 @@ def load():
     lib.vqcpc_encoder_context.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.vqcpc_encoder_stage.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.vqcpc_encoder_vq_encode.argtypes = [vp, vp, i32, vp, i64p, vp]
+    lib.vqcpc_encoder_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.vqcpc_vocoder_create.argtypes = [C.POINTER(VocoderWeights), C.POINTER(vp)]
     lib.vqcpc_vocoder_destroy.argtypes = [vp]
     lib.vqcpc_vocoder_destroy.restype = None

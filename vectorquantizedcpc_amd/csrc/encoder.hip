@@ -389,33 +389,28 @@ __device__ __forceinline__ void vq_take(const f32x4 &acc, int code, float e2, co
     }
 }
 
-__global__ __launch_bounds__(256) void vq_encode_kernel(const float *__restrict__ X, int N, const float4 *__restrict__ Ef,
-                                                        const float *__restrict__ E, const float *__restrict__ e2, int n_emb,
-                                                        int64_t *__restrict__ idx, float *__restrict__ zq) {
-    __shared__ float xs[16][68];
-    __shared__ float x2s[16];
-    __shared__ float cd[4][16];
-    __shared__ int cj[4][16];
-    __shared__ int best[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
-    {
-        const int row = tid >> 4, c4 = tid & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < N) v = ((const float4 *)X)[(size_t)(r0 + row) * 16 + c4];
-        xs[row][4 * c4 + 0] = v.x; xs[row][4 * c4 + 1] = v.y; xs[row][4 * c4 + 2] = v.z; xs[row][4 * c4 + 3] = v.w;
-    }
-    if (tid < 16) x2s[tid] = r0 + tid < N ? sumsq64(X + (size_t)(r0 + tid) * 64) : 0.f;
+// Shared tail of the VQ search: xs / x2s hold the 16 rows (and their |x|^2) of the block starting at row r0.
+struct VqSmem {
+    float xs[16][68];
+    float x2s[16];
+    float cd[4][16];
+    int cj[4][16];
+    int best[16];
+};
+__device__ __forceinline__ void vq_rows16(VqSmem &sm, int r0, int N, const float4 *__restrict__ Ef, const float *__restrict__ E,
+                                          const float *__restrict__ e2, int n_emb, int64_t *__restrict__ idx,
+                                          float *__restrict__ zq, int tid, const float4 (&f0_in)[4], const float4 (&f1_in)[4]) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int tpw = n_emb / 64, t0 = wave * tpw;                       // 16-code tiles per wave, this wave's first
     float4 f0[4], f1[4];
-    vq_load_tile(Ef, t0, lane, f0);
-    if (tpw > 1) vq_load_tile(Ef, t0 + 1, lane, f1);
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { f0[q] = f0_in[q]; f1[q] = f1_in[q]; }
     float a[16], x2[4], bd[4];
     int bj[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = xs[lane & 15][4 * j + (lane >> 4)];
+    for (int j = 0; j < 16; ++j) a[j] = sm.xs[lane & 15][4 * j + (lane >> 4)];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { x2[r] = x2s[4 * (lane >> 4) + r]; bd[r] = __builtin_inff(); bj[r] = 0; }
+    for (int r = 0; r < 4; ++r) { x2[r] = sm.x2s[4 * (lane >> 4) + r]; bd[r] = __builtin_inff(); bj[r] = 0; }
 
     int tt = 0;
     for (; tt + 1 < tpw; tt += 2) {
@@ -459,23 +454,282 @@ __global__ __launch_bounds__(256) void vq_encode_kernel(const float *__restrict_
             const int oj = __shfl_xor(bj[r], off);
             if (od < bd[r] || (od == bd[r] && oj < bj[r])) { bd[r] = od; bj[r] = oj; }
         }
-        if ((lane & 15) == 0) { cd[wave][4 * (lane >> 4) + r] = bd[r]; cj[wave][4 * (lane >> 4) + r] = bj[r]; }
+        if ((lane & 15) == 0) { sm.cd[wave][4 * (lane >> 4) + r] = bd[r]; sm.cj[wave][4 * (lane >> 4) + r] = bj[r]; }
     }
     __syncthreads();
     if (tid < 16) {
-        float d = cd[0][tid];
-        int j = cj[0][tid];
+        float d = sm.cd[0][tid];
+        int j = sm.cj[0][tid];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
-            if (cd[w][tid] < d) { d = cd[w][tid]; j = cj[w][tid]; }
-        best[tid] = j;
+            if (sm.cd[w][tid] < d) { d = sm.cd[w][tid]; j = sm.cj[w][tid]; }
+        sm.best[tid] = j;
         if (r0 + tid < N) idx[r0 + tid] = j;
     }
     __syncthreads();
     {
         const int row = tid >> 4, c4 = tid & 15;                       // F.embedding gather (model.py:113)
-        if (r0 + row < N) ((float4 *)zq)[(size_t)(r0 + row) * 16 + c4] = ((const float4 *)E)[(size_t)best[row] * 16 + c4];
+        if (r0 + row < N) ((float4 *)zq)[(size_t)(r0 + row) * 16 + c4] = ((const float4 *)E)[(size_t)sm.best[row] * 16 + c4];
     }
+}
+
+__global__ __launch_bounds__(256) void vq_encode_kernel(const float *__restrict__ X, int N, const float4 *__restrict__ Ef,
+                                                        const float *__restrict__ E, const float *__restrict__ e2, int n_emb,
+                                                        int64_t *__restrict__ idx, float *__restrict__ zq) {
+    __shared__ VqSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
+    {
+        const int row = tid >> 4, c4 = tid & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < N) v = ((const float4 *)X)[(size_t)(r0 + row) * 16 + c4];
+        sm.xs[row][4 * c4 + 0] = v.x; sm.xs[row][4 * c4 + 1] = v.y; sm.xs[row][4 * c4 + 2] = v.z; sm.xs[row][4 * c4 + 3] = v.w;
+    }
+    if (tid < 16) sm.x2s[tid] = r0 + tid < N ? sumsq64(X + (size_t)(r0 + tid) * 64) : 0.f;
+    const int tpw = n_emb / 64, t0 = wave * tpw;
+    float4 f0[4], f1[4];
+    vq_load_tile(Ef, t0, lane, f0);
+    if (tpw > 1) vq_load_tile(Ef, t0 + 1, lane, f1);
+    else vq_load_tile(Ef, t0, lane, f1);
+    __syncthreads();
+    vq_rows16(sm, r0, N, Ef, E, e2, n_emb, idx, zq, tid, f0, f1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused front end: conv -> LN/ReLU -> 4 x (FC -> LN/ReLU) -> FC 512->64 -> VQ in ONE launch, 16 rows per workgroup.
+//
+// The layered path above moves every activation through HBM ten times and spends 22 % of a C2 call in stand-alone
+// LayerNorm passes (DESIGN "Encoder").  Here a 256-thread workgroup owns 16 whole rows: the activation tile
+// (16 x 512 fp32) lives in LDS from the im2col gather to the VQ search, LayerNorm runs on it in place (the same
+// half-wave-per-row Welford cascade as ln512_kernel, so the same bits), and each wave multiplies it with 128 output
+// columns at a time on v_mfma_f32_16x16x4_f32: weights are pre-arranged in fragment order
+//   Wf[(ct * K/16 + q) * 64 + lane] (float4) = W[16 ct + (lane & 15)][16 q + 4 c + (lane >> 4)], c = .x .y .z .w
+// and go from L2 straight to registers (16 B per lane per 4 MFMAs, requested 3 q-steps ahead); one MFMA covers 4
+// consecutive k, one accumulator per 16 x 16 tile, so a dot product is the same k-ascending fmaf chain -- restarted at
+// the reference's K-block boundaries -- that gemm_chain_kernel runs on 32x32x2 tiles.  Same bits, one launch, no
+// activation traffic; per workgroup the stream is all 5 MB of weights (L2-resident: every workgroup reads the same).
+// ------------------------------------------------------------------------------------------
+#define FE_LD 514                       // LDS row stride of the activation tile: bank = 2 row + k, conflict-free A reads
+
+__global__ void frag16_build_kernel(const float *__restrict__ W, int N, int K, float4 *__restrict__ Wf) {
+    const int nq = K / 16;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)(N / 16) * nq * 64) return;
+    const int lane = (int)(id & 63);
+    const int q = (int)((id >> 6) % nq), ct = (int)((id >> 6) / nq);
+    const float *r = W + (size_t)(16 * ct + (lane & 15)) * K + 16 * q + (lane >> 4);
+    Wf[id] = make_float4(r[0], r[4], r[8], r[12]);
+}
+
+struct FusedP {
+    const float *mel; int C, T, To, N;
+    int conv_mode;                      // 1 im2col order (one chain), 2 direct order (chain restarted every 64 k)
+    const float4 *conv_f;               // conv weight fragments in that order: [32 ct][K/16][64]
+    const float *ln_g[5], *ln_b[5];
+    const float4 *fc_f[4];              // [32 ct][32][64]
+    const float4 *out_f; const float *out_b;   // [4 ct][32][64]
+    const float4 *Ef; const float *E, *e2; int n_emb;
+    float *z_pre; float *z_q; int64_t *idx;
+    float *stage_out; int stage;        // stage dump (vqcpc_encoder_stage): -1 = none
+    float eps; LnConst lnc;
+};
+
+// One GEMM stage for this wave: tile (LDS, 16 rows x K) x NT column tiles starting at ct0.  tot = fold over K blocks of
+// kcq q-steps (16 k each) of zero-started chains: first block (bias ? bias + chain : chain), later blocks tot + chain.
+template <int NT>
+__device__ __forceinline__ void rows16_gemm(const float *tile, const float4 *__restrict__ Wf, int ct0, int nq, int kcq,
+                                            const float *__restrict__ bias, f32x4 (&tot)[NT], int lane) {
+    const float4 *wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = Wf + ((size_t)(ct0 + j) * nq) * 64 + lane;
+    float4 fr[4][NT];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fr[u][j] = wp[j][(size_t)(u < nq ? u : nq - 1) * 64];
+    const float *arow = tile + (lane & 15) * FE_LD + (lane >> 4);
+    float an[4] = {arow[0], arow[4], arow[8], arow[12]};
+    f32x4 acc[NT];
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tot[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[j] = bias ? bias[16 * (ct0 + j) + (lane & 15)] : 0.f;
+    }
+    bool first = true;
+    for (int q0 = 0; q0 < nq; q0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u;
+            const int qp = q + 3 < nq ? q + 3 : nq - 1;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fr[(u + 3) & 3][j] = wp[j][(size_t)qp * 64];
+            const float a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+            const int qn = q + 1 < nq ? q + 1 : q;
+            an[0] = arow[16 * qn]; an[1] = arow[16 * qn + 4]; an[2] = arow[16 * qn + 8]; an[3] = arow[16 * qn + 12];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, fr[u][j].x, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, fr[u][j].y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, fr[u][j].z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, fr[u][j].w, acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((q0 + 4) % kcq == 0) {                                   // end of a K block (kcq is a multiple of 4)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    tot[j][r] = first ? (bias ? bv[j] + acc[j][r] : acc[j][r]) : tot[j][r] + acc[j][r];
+                    acc[j][r] = 0.f;
+                }
+            }
+            first = false;
+        }
+    }
+}
+
+// D layout of the 16x16x4 MFMA: register r of a lane = row 4 (lane >> 4) + r, column lane & 15.
+template <int NT>
+__device__ __forceinline__ void rows16_store(float *tile, const f32x4 (&tot)[NT], int ct0, int lane) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * (lane >> 4) + r) * FE_LD + 16 * (ct0 + j) + (lane & 15)] = tot[j][r];
+}
+
+// LayerNorm(512) + ReLU of the tile in place: the half-wave-per-row procedure of ln512_kernel (ATen's order), two rounds
+// of 8 rows; the half-wave that computed a row's moments also normalises it.
+__device__ __forceinline__ void rows16_layernorm(float *tile, const float *__restrict__ g, const float *__restrict__ b,
+                                                 float eps, const LnConst &k, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, ll = lane & 31;
+    const int chunk = ll >> 3, l = ll & 7;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        float *x = tile + (round * 8 + wave * 2 + half) * FE_LD;
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float xv = x[(chunk * 16 + j) * 8 + l];
+            const float d = xv - m1;
+            m1 = __builtin_fmaf(d, k.inv[j], m1);
+            m2 = __builtin_fmaf(d, xv - m1, m2);
+        }
+        float a1 = __shfl_down(m1, 8), a2 = __shfl_down(m2, 8);
+        {
+            const float delta = a1 - m1;
+            const float n1 = __builtin_fmaf(0.5f, delta, m1);
+            m2 = __builtin_fmaf((0.5f * 16.0f) * delta, delta, m2 + a2);
+            m1 = n1;
+        }
+        a1 = __shfl_down(m1, 16); a2 = __shfl_down(m2, 16);
+        {
+            const float delta = a1 - m1;
+            const float n1 = __builtin_fmaf(0.5f, delta, m1);
+            m2 = __builtin_fmaf((0.5f * 32.0f) * delta, delta, m2 + a2);
+            m1 = n1;
+        }
+        float M1 = 0.f, M2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float s1 = __shfl(m1, half * 32 + q), s2 = __shfl(m2, half * 32 + q);
+            const float delta = s1 - M1;
+            M1 = __builtin_fmaf(k.sc[q], delta, M1);
+            M2 = M2 + __builtin_fmaf((delta * delta) * k.sc[q], (float)(64 * q), s2);
+        }
+        const float mean = M1, var = M2 / 512.0f;
+        const float sd = (float)sqrt((double)(var + eps));
+        const float rstd = (float)(1.0 / (double)sd);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = q * 64 + ll * 2;                              // 8-byte LDS accesses (the row stride is 8 mod 16)
+            const float2 xv = *(const float2 *)(x + e);
+            const float2 gv = *(const float2 *)(g + e);
+            const float2 bb = *(const float2 *)(b + e);
+            float2 o;
+            o.x = __builtin_fmaf((xv.x - mean) * rstd, gv.x, bb.x);
+            o.y = __builtin_fmaf((xv.y - mean) * rstd, gv.y, bb.y);
+            o.x = o.x < 0.f ? 0.f : o.x;
+            o.y = o.y < 0.f ? 0.f : o.y;
+            *(float2 *)(x + e) = o;
+        }
+    }
+}
+
+__device__ __forceinline__ bool rows16_dump(const FusedP &p, const float *tile, int stage, int r0, int tid) {
+    if (p.stage != stage) return false;
+    for (int e = tid; e < 16 * 512; e += 256) {
+        const int row = e >> 9, col = e & 511;
+        if (r0 + row < p.N) p.stage_out[(size_t)(r0 + row) * 512 + col] = tile[row * FE_LD + col];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
+    __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
+    __shared__ VqSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
+    const int K0 = 4 * p.C;
+
+    // ---- im2col gather of the 16 rows (model.py:65), k order of the reference back end (fetch_a)
+    for (int e = tid; e < 16 * K0; e += 256) {
+        const int i = e & 15, kidx = e >> 4, m = r0 + i;
+        int c, tap;
+        if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
+        else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
+        float v = 0.f;
+        if (m < p.N) {
+            const int b = m / p.To, tt = m - b * p.To, ti = 2 * tt + tap - 1;
+            if (ti >= 0 && ti < p.T) v = p.mel[((size_t)b * p.C + c) * p.T + ti];
+        }
+        tile[i * FE_LD + kidx] = v;
+    }
+    __syncthreads();
+
+    f32x4 tot[8];
+    rows16_gemm<8>(tile, p.conv_f, 8 * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane);
+    __syncthreads();                                     // every wave has read its A operands
+    rows16_store<8>(tile, tot, 8 * wave, lane);
+    __syncthreads();
+    if (rows16_dump(p, tile, 0, r0, tid)) return;
+
+    // ---- seg-FC stack (model.py:46-55)
+    rows16_layernorm(tile, p.ln_g[0], p.ln_b[0], p.eps, p.lnc, tid);
+    __syncthreads();
+    if (rows16_dump(p, tile, 1, r0, tid)) return;
+    for (int l = 0; l < 4; ++l) {
+        rows16_gemm<8>(tile, p.fc_f[l], 8 * wave, 32, 16, nullptr, tot, lane);
+        __syncthreads();
+        rows16_store<8>(tile, tot, 8 * wave, lane);
+        __syncthreads();
+        if (rows16_dump(p, tile, 2 + 2 * l, r0, tid)) return;
+        rows16_layernorm(tile, p.ln_g[l + 1], p.ln_b[l + 1], p.eps, p.lnc, tid);
+        __syncthreads();
+        if (rows16_dump(p, tile, 3 + 2 * l, r0, tid)) return;
+    }
+
+    // ---- encoder.14: 512 -> 64 with bias; one 16-column tile per wave; the VQ codebook tiles stream in underneath
+    const int tpw = p.n_emb / 64, t0 = wave * tpw;
+    float4 f0[4], f1[4];
+    vq_load_tile(p.Ef, t0, lane, f0);
+    vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
+    f32x4 zt[1];
+    rows16_gemm<1>(tile, p.out_f, wave, 32, 16, p.out_b, zt, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
+        sm.xs[row][col] = zt[0][r];
+        if (p.z_pre && r0 + row < p.N) p.z_pre[(size_t)(r0 + row) * 64 + col] = zt[0][r];
+    }
+    __syncthreads();
+    if (p.stage == 10) return;                           // z_pre is the stage output
+    // ---- VQ (model.py:103-115)
+    if (tid < 16) sm.x2s[tid] = r0 + tid < p.N ? sumsq64(&sm.xs[tid][0]) : 0.f;
+    __syncthreads();
+    vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1);
 }
 
 // Eval-branch statistics of VQEmbeddingEMA.forward (model.py:147-153): deterministic two-level
@@ -550,6 +804,9 @@ struct vqcpc_encoder {
     LstmPlan *lstm = nullptr;
     LnConst lnc;
     DevBuf bufA, bufB, zpre, stats;
+    // fused front end (enc_fused_kernel): weights in 16x16x4 fragment order
+    float4 *conv_f[2] = {nullptr, nullptr}, *fc_f[4] = {}, *out_f = nullptr;
+    int fused = -1;                      // -1 auto (fused when the layout supports it), 0 layered kernels, 1 fused
 };
 
 static int dev_copy(float **dst, const float *src, size_t n) {
@@ -566,9 +823,20 @@ extern "C" void vqcpc_encoder_destroy(vqcpc_encoder *e) {
     for (int i = 0; i < 5; ++i) { if (e->ln_g[i]) (void)hipFree(e->ln_g[i]); if (e->ln_b[i]) (void)hipFree(e->ln_b[i]); }
     for (int i = 0; i < 4; ++i) if (e->fc_w[i]) (void)hipFree(e->fc_w[i]);
     if (e->lstm) vq_lstm_plan_destroy(e->lstm);
+    float4 *fr[] = {e->conv_f[0], e->conv_f[1], e->fc_f[0], e->fc_f[1], e->fc_f[2], e->fc_f[3], e->out_f};
+    for (float4 *q : fr) if (q) (void)hipFree(q);
     e->bufA.release(); e->bufB.release();
     e->zpre.release(); e->stats.release();
     delete e;
+}
+
+static int build_frag16(const float *W, int N, int K, float4 **out) {
+    VQ_REQUIRE(N % 16 == 0 && K % 64 == 0, "build_frag16: unsupported shape (%d, %d)", N, K);
+    const size_t n4 = (size_t)(N / 16) * (K / 16) * 64;
+    HIP_TRY(hipMalloc((void **)out, n4 * sizeof(float4)));
+    hipLaunchKernelGGL(frag16_build_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, W, N, K, *out);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
 }
 
 static int encoder_create_impl(const vqcpc_encoder_weights *w, vqcpc_encoder *e) {
@@ -595,6 +863,13 @@ static int encoder_create_impl(const vqcpc_encoder_weights *w, vqcpc_encoder *e)
                        (float4 *)e->cbfrag, w->n_embeddings);
     HIP_TRY(hipGetLastError());
     TRY(vq_lstm_plan_create(w->rnn_w_ih, w->rnn_w_hh, w->rnn_b_ih, w->rnn_b_hh, w->z_dim, w->c_dim, &e->lstm));
+    // fragment-ordered copies for the fused front end (the activation tile is 512 wide: 4 C <= 512)
+    if (4 * C <= 512) {
+        TRY(build_frag16(e->conv_w1, CH, 4 * C, &e->conv_f[0]));
+        TRY(build_frag16(e->conv_w2, CH, 4 * C, &e->conv_f[1]));
+        for (int i = 0; i < 4; ++i) TRY(build_frag16(e->fc_w[i], CH, CH, &e->fc_f[i]));
+        TRY(build_frag16(e->out_w, w->z_dim, CH, &e->out_f));
+    }
     HIP_TRY(hipDeviceSynchronize());
     return VQCPC_OK;
 }
@@ -658,6 +933,40 @@ static int encoder_front(vqcpc_encoder *e, const float *mel, int B, int T, int c
     return VQCPC_OK;
 }
 
+static bool use_fused(const vqcpc_encoder *e) { return e->fused != 0 && e->conv_f[0] != nullptr; }
+
+// The whole front end + VQ in one launch (stage < 0), or up to `stage` with that stage's rows in stage_out.
+static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode, float *z_pre, float *z_q,
+                         int64_t *idx, int stage, float *stage_out, hipStream_t s) {
+    const int C = e->in_channels, To = (T - 2) / 2 + 1, N = B * To;
+    if (conv_mode == VQCPC_CONV_AUTO)
+        conv_mode = (B > 1 || (long)B * C * T > 20480) ? VQCPC_CONV_DIRECT : VQCPC_CONV_IM2COL;
+    FusedP p{};
+    p.mel = mel; p.C = C; p.T = T; p.To = To; p.N = N; p.conv_mode = conv_mode;
+    p.conv_f = e->conv_f[conv_mode == VQCPC_CONV_IM2COL ? 0 : 1];
+    for (int i = 0; i < 5; ++i) { p.ln_g[i] = e->ln_g[i]; p.ln_b[i] = e->ln_b[i]; }
+    for (int i = 0; i < 4; ++i) p.fc_f[i] = e->fc_f[i];
+    p.out_f = e->out_f; p.out_b = e->out_b;
+    p.Ef = (const float4 *)e->cbfrag; p.E = e->codebook; p.e2 = e->e2; p.n_emb = e->n_emb;
+    p.z_pre = z_pre; p.z_q = z_q; p.idx = idx; p.stage_out = stage_out; p.stage = stage;
+    p.eps = 1e-5f; p.lnc = e->lnc;
+    hipLaunchKernelGGL(enc_fused_kernel, dim3((N + 15) / 16), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+extern "C" int vqcpc_encoder_set_option(vqcpc_encoder *e, const char *name, int value) {
+    VQ_REQUIRE(e && name, "vqcpc_encoder_set_option: null argument");
+    if (!strcmp(name, "fused")) {
+        VQ_REQUIRE(value >= -1 && value <= 1, "fused must be -1 (auto), 0 or 1");
+        VQ_REQUIRE(value != 1 || e->conv_f[0], "fused front end needs 4 * in_channels <= 512");
+        e->fused = value;
+        return VQCPC_OK;
+    }
+    vq_set_error("unknown option %s", name);
+    return VQCPC_ERR_INVALID;
+}
+
 extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, int T, int conv_mode,
                                     float *z_q, float *c, int64_t *idx, float *z_pre, void *stream) {
     VQ_REQUIRE(e && mel && z_q && idx, "vqcpc_encoder_encode: null argument");
@@ -666,15 +975,18 @@ extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, i
     hipStream_t s = (hipStream_t)stream;
     const int To = (T - 2) / 2 + 1, N = B * To;
     float *zp = z_pre;
-    if (!zp) { TRY(e->zpre.reserve((size_t)N * 64 * sizeof(float))); zp = e->zpre.as<float>(); }
+    if (!zp && !use_fused(e)) { TRY(e->zpre.reserve((size_t)N * 64 * sizeof(float))); zp = e->zpre.as<float>(); }
     VQ_REQUIRE(((uintptr_t)zp & 15) == 0 && ((uintptr_t)z_q & 15) == 0, "encoder.encode: outputs must be 16-byte aligned");
-    const float *unused = nullptr;
-    TRY(encoder_front(e, mel, B, T, conv_mode, 10, zp, &unused, s));
-
-    // VQ (model.py:103-115)
-    hipLaunchKernelGGL(vq_encode_kernel, dim3((N + 15) / 16), dim3(256), 0, s, zp, N, (const float4 *)e->cbfrag, e->codebook,
-                       e->e2, e->n_emb, idx, z_q);
-    HIP_TRY(hipGetLastError());
+    if (use_fused(e)) {
+        TRY(encoder_fused(e, mel, B, T, conv_mode, z_pre, z_q, idx, -1, nullptr, s));     // z_pre only if asked for
+    } else {
+        const float *unused = nullptr;
+        TRY(encoder_front(e, mel, B, T, conv_mode, 10, zp, &unused, s));
+        // VQ (model.py:103-115)
+        hipLaunchKernelGGL(vq_encode_kernel, dim3((N + 15) / 16), dim3(256), 0, s, zp, N, (const float4 *)e->cbfrag, e->codebook,
+                           e->e2, e->n_emb, idx, z_q);
+        HIP_TRY(hipGetLastError());
+    }
     if (c) TRY(vq_lstm_run(e->lstm, z_q, B, To, c, s));
     return VQCPC_OK;
 }
@@ -695,6 +1007,9 @@ extern "C" int vqcpc_encoder_stage(vqcpc_encoder *e, const float *mel, int B, in
     VQ_REQUIRE(B > 0 && T >= 2 && stage >= 0 && stage <= 10, "vqcpc_encoder_stage: bad shape or stage");
     hipStream_t s = (hipStream_t)stream;
     const int N = B * ((T - 2) / 2 + 1);
+    if (use_fused(e))                                    // the fused kernel stops after `stage` and dumps its tile
+        return encoder_fused(e, mel, B, T, conv_mode, stage == 10 ? out : nullptr, nullptr, nullptr, stage,
+                             stage == 10 ? nullptr : out, s);
     const float *src = nullptr;
     float *zp = nullptr;
     if (stage == 10) {

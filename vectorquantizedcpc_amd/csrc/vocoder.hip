@@ -315,10 +315,15 @@ extern "C" int vqcpc_debug_ar_stamps(unsigned long long *out) {
 #endif
 
 struct ArModel {               // constant per handle (baked into the captured graph)
-    const float *b_hh, *Gemb;
+    // Cell-update operands in "unit quads": for row group rg (4 hidden units) and unit u, ONE float4 = (r, z, n, 0).
+    // A gate wave's lane then needs one 16-byte load per table instead of three 4-byte loads H apart, and the 16
+    // slots of a tile read 1 KiB contiguous (gcur4) -- the [3H] layouts cost a whole 128-B line per 16 bytes used.
+    const float4 *bh4;         // [Hr/4][4]            b_hh
+    const float4 *Gemb4;       // [n_cls][Hr/4][4]     emb . W_ih[:, :de]^T
+    const float *Gemb;         // [n_cls][3Hr] (unused by the step kernels; kept for tools)
     const float *Wf_hh12;      // W_hh in packed 12-row groups (ar_gru_kernel: no padding rows streamed)
     const float *Wf_hh16;      // W_hh in gate-major 16-row tiles (large-batch kernel: no padding rows)
-    float *gcur;               // [Sp][3Hr] the Gcond row every slot uses during the replay in flight (gc_replay)
+    float4 *gcur4;             // [Hr/4][Sp][4] the Gcond row every slot uses during the replay in flight (gc_replay), unit quads
     int gc_replay;             // 1: upsample % steps_per_graph == 0, so a slot stays on one conditioning frame per replay
     int live_last;             // decode slots in use in the last tile (1..16): lanes of dead columns re-read column 0
     int lead6;                 // ar_gru_kernel requests fragments 6 super-steps ahead instead of 3 (see there)
@@ -475,14 +480,12 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             load_candidates16(m, sg, cd);
             const ArSlot sl = m.cur[sg];
             const ArCall c = *cp;
-            const float *bh = m.b_hh + unit;
-            bh0 = bh[0]; bh1 = bh[Hr]; bh2 = bh[2 * Hr];
+            const float4 bq = m.bh4[rg * 4 + u];
             hi = hl_index(Hr, sg, unit);
             const float hprev = hin[hi];
-            {                                                            // no branch around loads: gcur always exists
-                const float *gc = m.gcur + (size_t)sg * 3 * Hr + unit;
-                gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
-            }
+            const float4 gq = m.gcur4[((size_t)rg * (nbt * 16) + sg) * 4 + u];     // no branch around loads: gcur4 always exists
+            bh0 = bq.x; bh1 = bq.y; bh2 = bq.z;
+            gc0 = gq.x; gc1 = gq.y; gc2 = gq.z;
             float4 mtl = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rg == 0 && wave == 0) mtl = ((const float4 *)m.mulaw_tab)[4 * lane < m.n_cls ? lane : 0];
             __builtin_amdgcn_sched_barrier(0);
@@ -502,8 +505,8 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
                                 mulp = c.mulaw ? c.mulaw + (size_t)sl.row * c.Lout + lt - 1 : nullptr; xraw = x; }
                 }
                 x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
-                const float *ge = m.Gemb + (size_t)x * 3 * Hr + unit;
-                ge0 = ge[0]; ge1 = ge[Hr]; ge2 = ge[2 * Hr];
+                const float4 eq = m.Gemb4[((size_t)x * (Hr >> 2) + rg) * 4 + u];
+                ge0 = eq.x; ge1 = eq.y; ge2 = eq.z;
                 if (!m.gc_replay) {
                     const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
                     gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
@@ -593,10 +596,11 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
         const ArCall c = *cp;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int unit = 16 * blk + 8 * uh + 4 * p + u;
-            const float *pb = m.b_hh + unit, *pg = m.gcur + (size_t)sg * 3 * Hr + unit;
-            bh[p][0] = pb[0]; bh[p][1] = pb[Hr]; bh[p][2] = pb[2 * Hr];
-            gc[p][0] = pg[0]; gc[p][1] = pg[Hr]; gc[p][2] = pg[2 * Hr];
+            const int unit = 16 * blk + 8 * uh + 4 * p + u, rgq = 4 * blk + 2 * uh + p;
+            const float4 bq = m.bh4[rgq * 4 + u];
+            const float4 gq = m.gcur4[((size_t)rgq * (nbt * 16) + sg) * 4 + u];
+            bh[p][0] = bq.x; bh[p][1] = bq.y; bh[p][2] = bq.z;
+            gc[p][0] = gq.x; gc[p][1] = gq.y; gc[p][2] = gq.z;
             hi[p] = hl_index(Hr, sg, unit);
             hprev[p] = hin[hi[p]];
         }
@@ -622,9 +626,9 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
             x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int unit = 16 * blk + 8 * uh + 4 * p + u;
-                const float *pe = m.Gemb + (size_t)x * 3 * Hr + unit;
-                ge[p][0] = pe[0]; ge[p][1] = pe[Hr]; ge[p][2] = pe[2 * Hr];
+                const int unit = 16 * blk + 8 * uh + 4 * p + u, rgq = 4 * blk + 2 * uh + p;
+                const float4 eq = m.Gemb4[((size_t)x * (Hr >> 2) + rgq) * 4 + u];
+                ge[p][0] = eq.x; ge[p][1] = eq.y; ge[p][2] = eq.z;
                 if (!m.gc_replay) {
                     const float *pg = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
                     gc[p][0] = pg[0]; gc[p][1] = pg[Hr]; gc[p][2] = pg[2 * Hr];
@@ -797,9 +801,26 @@ __global__ __launch_bounds__(256) void ar_next_row_kernel(ArModel m, const ArCal
     if (!m.gc_replay || sl.row < 0 || c.t_base < sl.t0) return;
     const int f = (c.t_base - sl.t0) / m.upsample;
     if (f >= c.F) return;
-    const float4 *src = (const float4 *)(c.Gcond + ((size_t)sl.row * c.F + f) * 3 * m.Hr);
-    float4 *dst = (float4 *)(m.gcur + (size_t)sg * 3 * m.Hr);
-    for (int i = threadIdx.x; i < 3 * m.Hr / 4; i += 256) dst[i] = src[i];
+    const float *src = c.Gcond + ((size_t)sl.row * c.F + f) * 3 * m.Hr;
+    for (int rg = threadIdx.x; rg < (m.Hr >> 2); rg += 256) {           // [3][Hr] row -> unit quads of row group rg
+        const float4 r4 = *(const float4 *)(src + 4 * rg), z4 = *(const float4 *)(src + m.Hr + 4 * rg),
+                     n4 = *(const float4 *)(src + 2 * m.Hr + 4 * rg);
+        float4 *dst = m.gcur4 + ((size_t)rg * c.Sp + sg) * 4;
+        dst[0] = make_float4(r4.x, z4.x, n4.x, 0.f);
+        dst[1] = make_float4(r4.y, z4.y, n4.y, 0.f);
+        dst[2] = make_float4(r4.z, z4.z, n4.z, 0.f);
+        dst[3] = make_float4(r4.w, z4.w, n4.w, 0.f);
+    }
+}
+
+// [rows][3][H] -> unit quads [rows][H/4][4] float4 (r, z, n, 0)
+__global__ void quads_build_kernel(const float *__restrict__ src, float4 *__restrict__ dst, int rows, int H) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)rows * H) return;
+    const int unit = (int)(id % H);
+    const size_t row = id / H;
+    const float *s = src + row * 3 * H + unit;
+    dst[row * H + unit] = make_float4(s[0], s[H], s[2 * H], 0.f);
 }
 
 // Bounded delay (~cycles shader clocks): offsets the second tile group by about half a sample step.
@@ -868,6 +889,7 @@ struct vqcpc_vocoder {
     float *code_emb = nullptr, *spk_emb = nullptr;
     float *p_wih[2] = {}, *p_bih[2] = {}, *p_bhh[2] = {}, *p_wf[2] = {};   // per layer, both directions stacked
     float *w_cond = nullptr, *b_ih = nullptr, *Gemb = nullptr;
+    float4 *Gemb4 = nullptr, *bh4 = nullptr;
     float *Wf_hh12 = nullptr, *Wf_hh16 = nullptr, *b_hh = nullptr, *Wf_fc1 = nullptr, *Wf_fc1h = nullptr, *b_fc1 = nullptr, *Wf_fc2 = nullptr, *b_fc2 = nullptr;
     float *w_fc1 = nullptr, *w_fc2 = nullptr;      // plain (rows, K) copies for the teacher-forced scan's batched GEMMs
     float *mulaw_tab = nullptr;
@@ -919,6 +941,8 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
                      v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh12, v->Wf_hh16, v->b_hh,
                      v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab, v->w_fc1, v->w_fc2};
     for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (v->Gemb4) (void)hipFree(v->Gemb4);
+    if (v->bh4) (void)hipFree(v->bh4);
     DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
@@ -964,6 +988,11 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     float *emb = nullptr;
     TRY(dcopy(&emb, w->ar_embedding, (size_t)w->n_cls * de));
     TRY(vq_gemm_chain(emb, de, w_emb, nullptr, v->Gemb, 3 * Hr, w->n_cls, 3 * Hr, de, de, 0));
+    HIP_TRY(hipMalloc((void **)&v->Gemb4, (size_t)w->n_cls * Hr * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&v->bh4, (size_t)Hr * sizeof(float4)));
+    hipLaunchKernelGGL(quads_build_kernel, dim3((unsigned)(((size_t)w->n_cls * Hr + 255) / 256)), dim3(256), 0, 0, v->Gemb, v->Gemb4, w->n_cls, Hr);
+    hipLaunchKernelGGL(quads_build_kernel, dim3((unsigned)((Hr + 255) / 256)), dim3(256), 0, 0, v->b_hh, v->bh4, 1, Hr);
+    HIP_TRY(hipGetLastError());
     TRY(build_wfrag12(w->ar_w_hh, Hr, Hr / 4, Hr, Hr, &v->Wf_hh12));
     if (Hr % 16 == 0) TRY(build_wfrag(w->ar_w_hh, Hr, 3 * (Hr / 16), Hr, 4, 16, Hr, &v->Wf_hh16));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 16, Hr, 4, 0, 0, &v->Wf_fc1));
@@ -1234,7 +1263,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         TRY(G.a1.reserve((size_t)nb * d.Hf * 16 * sizeof(float)));
         TRY(G.cand_s.reserve((size_t)Spg * 16 * sizeof(float)));
         TRY(G.cand_k.reserve((size_t)Spg * 16 * sizeof(int)));
-        TRY(G.gcur.reserve((size_t)Spg * 3 * Hr * sizeof(float)));
+        TRY(G.gcur.reserve((size_t)Spg * Hr * sizeof(float4)));
         HIP_TRY(hipMemsetAsync(G.har.p, 0, 2 * hsz, s));
         HIP_TRY(hipMemsetAsync(G.cand_s.p, 0, (size_t)Spg * 16 * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(G.cand_k.p, 0, (size_t)Spg * 16 * sizeof(int), s));
@@ -1253,9 +1282,9 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
         ArModel &m = models[g];
         m = ArModel{};
-        m.Wf_hh12 = v->Wf_hh12; m.Wf_hh16 = v->Wf_hh16; m.b_hh = v->b_hh; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
+        m.Wf_hh12 = v->Wf_hh12; m.Wf_hh16 = v->Wf_hh16; m.bh4 = v->bh4; m.Gemb4 = v->Gemb4; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
         m.Wf_fc2 = v->Wf_fc2; m.b_fc2 = v->b_fc2; m.mulaw_tab = v->mulaw_tab;
-        m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>(); m.cur = G.cur.as<ArSlot>(); m.gcur = G.gcur.as<float>();
+        m.hbuf = G.har.as<float>(); m.a1 = G.a1.as<float>(); m.cand_s = G.cand_s.as<float>(); m.cand_k = G.cand_k.as<int>(); m.cur = G.cur.as<ArSlot>(); m.gcur4 = G.gcur.as<float4>();
         m.gc_replay = d.upsample_t % S == 0;
         {
             const int live = (n_slots - slot0[g] < Spg ? n_slots - slot0[g] : Spg) - (nb - 1) * 16;

@@ -169,6 +169,10 @@ class Encoder(nn.Module):
         super().__setstate__(state)
         self.codebook._owner = weakref.ref(self)
 
+    def set_option(self, name: str, value: int):
+        """``vqcpc_encoder_set_option`` (``fused``: -1 auto, 0 layered kernels, 1 fused front end)."""
+        _lib.check(_lib.load().vqcpc_encoder_set_option(self._native(), name.encode(), int(value)))
+
     def refresh(self):
         """Drop the native handle so that the next call re-reads the parameters.  The handle holds re-laid
         COPIES of the weights and is rebuilt automatically when a parameter's storage or ``_version`` changes
