@@ -197,7 +197,7 @@ def test_vq_embedding_encode_and_forward_standalone(golden_dir):
     assert torch.equal(q2, zf) and float(loss2) == float(loss) and float(ppl2) == float(ppl)
     with pytest.raises(RuntimeError):
         enc.codebook.encode(z_pre.cpu())
-    w = enc.encoder[2].weight
+    w = enc.encoder[14].weight                         # (a LayerNorm follows every other Linear and would undo a scale)
     w.data.mul_(2.0)                                   # a write through .data bumps no version: refresh() re-reads
     try:
         assert torch.equal(enc.encode(melc)[2], idx)
