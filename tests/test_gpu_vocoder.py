@@ -319,3 +319,30 @@ def test_teacher_forced_scan_chunks_and_training_shape():
     x2 = torch.cat([x[:, :200], synth.randint("tf2/x2", (B2 - B, 200), 256)])
     d = voc(x2.cuda(), z2.cuda(), spk2.cuda())
     assert d.shape == (B2, 200, 256) and torch.equal(d[:B], a[:, :200])
+
+
+def test_persistent_single_utterance_decoder():
+    """BASELINE configs[2]: one utterance runs on the persistent decoder (weights resident in registers, in-kernel
+    granule exchanges).  It must produce the bits of the launch-per-step kernels (same fmaf chains), so an utterance
+    alone still equals itself inside a batch; and it is checked against the oracle directly, draw by draw."""
+    voc, sd = vocoder()
+    z = synth.randint("ps/z", (1, 4), 512)
+    spk = torch.tensor([7])
+    try:
+        voc.set_option("persistent", 0)
+        w0, m0 = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=3, return_mulaw=True)
+        t0 = voc.last_timing()
+        voc.set_option("persistent", 1)
+        w1, m1 = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=3, return_mulaw=True)
+        t1 = voc.last_timing()
+        w2, m2 = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=3, return_mulaw=True, max_steps=333)
+    finally:
+        voc.set_option("persistent", -1)
+    print("us per sample: launch-per-step %.2f, persistent %.2f" % (t0[0] * 1e3 / t0[1], t1[0] * 1e3 / t1[1]))
+    assert m0.shape == (1, 1280) and int((m0 != 0).sum()) > 1000
+    assert torch.equal(m0, m1) and torch.equal(w0, w1)
+    assert torch.equal(m2[0, :333], m0[0, :333]) and not m2[0, 333:].any() and not w2[0, 333:].any()
+    stats = _check_free_run(voc, sd, z, spk, None, seed=13, utt_base=3, steps=600)      # default options: persistent
+    assert stats[0][1] >= 0.999 * stats[0][0]
+    with pytest.raises(RuntimeError):
+        voc.kernel_times(10)               # no launch-per-step state after a persistent call

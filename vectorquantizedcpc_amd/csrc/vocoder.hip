@@ -784,6 +784,302 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     AR_STAMP(tid == 0, 2, 3);
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent single-utterance decoder (BASELINE configs[2]: Vocoder.generate on ONE utterance).
+//
+// One utterance cannot amortise the per-sample kernel boundaries (3 x 1.5 us) nor the re-fetch of 10.8 MB of weights
+// per step that they force (L2 does not keep lines across launches).  Here 64 workgroups stay resident for the whole
+// call and hold ALL weights in registers: workgroup j owns hidden units 14 j .. 14 j + 13 (42 gate rows of W_hh),
+// 4 rows of fc1 and 4 classes of fc2.  The three all-to-all mixes of a sample step (h_t, a_t, the 64 draw candidates)
+// are exchanged in-kernel as 8-byte {tag, value} granules (tag = step + 1) written with agent-scope relaxed atomics
+// (sc1 write-through stores) and swept by ONE wave per workgroup with agent-scope relaxed loads -- the data is the flag
+// (MI355X_MICROARCH.md "Valid forms", R2; cdna_hip_programming.md Guideline 16).  Single-buffered granules are safe:
+// nobody can produce step t+1's value of a word before every workgroup has consumed step t's (each later product
+// depends, through the next exchange, on every workgroup having finished the sweep that reads it).
+//
+// Arithmetic is BIT-IDENTICAL to the launch-per-step kernels: a v_mfma_f32_16x16x4_f32 chain is a sequence of fp32
+// fmas in a fixed k order (two accumulators per K quarter, x/z and y/w components of the fragment), so each lane here
+// runs one such chain with explicit fmaf and the partial sums are combined in the same order (a0 + a1, then
+// ((q0 + q1) + q2) + q3); cell update, fc epilogues, Gumbel-max draw are the same code.  Hence an utterance decoded
+// alone still equals the same utterance inside a batch bit for bit.
+//
+// Roles (512 threads): wave 0 = fc1 (lanes 0..31: 4 rows x 8 chains) and fc2 + draw (lanes 32..63: 4 classes x 8
+// chains); waves 1..6 = the 336 W_hh chains (42 rows x 8); wave 7 = service wave: sweeps the granules, merges the
+// candidates, runs the cell update of the 14 units and publishes.  Two workgroup barriers per sample.
+// Every spin is bounded (wall clock); a timeout raises an abort flag that every workgroup polls, and all waves leave.
+// ------------------------------------------------------------------------------------------
+#define PS_NB 64
+typedef unsigned long long u64;
+
+struct PersistP {
+    const float *w_hh, *w_fc1, *b_fc1, *w_fc2, *b_fc2;
+    const float4 *Gemb4, *bh4;
+    const float *Gcond;               // [F][3Hr] conditioning rows of this utterance (W_ih[:, de:] cond + b_ih)
+    const float *mulaw_tab;
+    u64 *gh, *ga, *gc;                // granules: [Hr] h_t, [Hf] a_t, [PS_NB] candidates
+    unsigned *abort_flag;
+    float *wav; int64_t *mulaw;
+    int n_steps, upsample, F;
+    unsigned utt; u64 seed;
+};
+
+__device__ __forceinline__ void ps_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ u64 ps_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ps_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// index of h[k] in the LDS copy: inside each 16-block, [component k % 4][k / 4 % 4], so that a chain reads the four
+// k of one MFMA as one 16-byte LDS word
+__device__ __forceinline__ int ps_perm(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+
+// one accumulator chain: NS super-steps of this K quarter, components c0 then c0 + 2 (the x/z or y/w MFMA operands)
+template <int NS>
+__device__ __forceinline__ float ps_chain(const float (&w)[8 * NS], const float4 *hb, int kw, int c0) {
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float4 h0 = hb[(kw * NS + s) * 4 + c0], h1 = hb[(kw * NS + s) * 4 + c0 + 2];
+        acc = __builtin_fmaf(w[8 * s + 0], h0.x, acc); acc = __builtin_fmaf(w[8 * s + 1], h0.y, acc);
+        acc = __builtin_fmaf(w[8 * s + 2], h0.z, acc); acc = __builtin_fmaf(w[8 * s + 3], h0.w, acc);
+        acc = __builtin_fmaf(w[8 * s + 4], h1.x, acc); acc = __builtin_fmaf(w[8 * s + 5], h1.y, acc);
+        acc = __builtin_fmaf(w[8 * s + 6], h1.z, acc); acc = __builtin_fmaf(w[8 * s + 7], h1.w, acc);
+    }
+    return acc;
+}
+template <int NS>
+__device__ __forceinline__ void ps_load_weights(const float *Wrow, int kw, int c0, float (&w)[8 * NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) w[8 * s + 4 * ci + kq] = Wrow[16 * (kw * NS + s) + 4 * kq + c0 + 2 * ci];
+}
+// the 8 chains of a row sit in 8 consecutive lanes (index 2 kw + a): returns, in the row's first lane, the row sum in
+// the order of the launch-per-step kernels
+__device__ __forceinline__ float ps_combine(float acc, int lane) {
+    const float other = __shfl_xor(acc, 1);
+    const float q = acc + other;                       // a0 + a1 (both lanes hold it)
+    const int base = lane & ~7;
+    const float q1 = __shfl(q, base + 2), q2 = __shfl(q, base + 4), q3 = __shfl(q, base + 6);
+    return ((q + q1) + q2) + q3;
+}
+
+// Sweep N granules per lane (stride 64) until every tag equals `tag`; bounded.  Returns false on timeout / abort.
+template <int N>
+__device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, unsigned tag, unsigned (&val)[N], unsigned *abort_flag) {
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const u64 x = ps_load(g + lane + 64 * j);
+            val[j] = (unsigned)x;
+            ok &= (unsigned)(x >> 32) == tag;
+        }
+        if (__all(ok)) return true;
+        if ((spins & 63) == 63) {
+            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;          // 1 s at 100 MHz
+            if (late || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (late && lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int SW>     // Hr = 64 SW; each of the 64 workgroups owns SW hidden units; Hf = n_cls = 256
+__global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
+    constexpr int Hr = 64 * SW, UPB = SW, NG = 3 * UPB * 8, Hf = 256, NC = 256, RPB = Hf / PS_NB;
+    __shared__ float4 gemb[NC * UPB];                                   // this workgroup's slice of the sample-embedding table
+    __shared__ __attribute__((aligned(16))) float hbuf[Hr];            // h_t, ps_perm order
+    __shared__ __attribute__((aligned(16))) float a1buf[Hf];           // a_t, ps_perm order
+    __shared__ float gsum[3 * UPB];                                     // W_hh h_{t-1} of the owned rows [gate][unit]
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    const int n = p.n_steps;
+
+    // ---- resident state: weights into registers, table slice into LDS
+    float w[8 * SW];
+    const int kw = (lane & 7) >> 1, c0 = lane & 1;
+    int row_local = 0;
+    bool gru_lane = false;
+    if (wave == 0) {
+        if (lane < 32) { row_local = lane >> 3; ps_load_weights<SW>(p.w_fc1 + (size_t)(RPB * blk + row_local) * Hr, kw, c0, w); }
+        else {
+            row_local = (lane - 32) >> 3;
+            float w2[8 * 4];
+            ps_load_weights<4>(p.w_fc2 + (size_t)(RPB * blk + row_local) * Hf, kw, c0, w2);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) w[i] = w2[i];
+        }
+    } else if (wave < 7) {
+        const int c = tid - 64;
+        gru_lane = c < NG;
+        row_local = gru_lane ? c >> 3 : 0;                                              // gate * UPB + unit
+        const int gate = row_local / UPB, ul = row_local - gate * UPB;
+        ps_load_weights<SW>(p.w_hh + (size_t)(gate * Hr + UPB * blk + ul) * Hr, kw, c0, w);
+    }
+    for (int e = tid; e < NC * UPB; e += 512) {
+        const int cls = e / UPB, unit = UPB * blk + (e - cls * UPB);
+        gemb[e] = p.Gemb4[((size_t)cls * (Hr >> 2) + (unit >> 2)) * 4 + (unit & 3)];
+    }
+    if (tid == 0) s_abort = 0;
+    // service-wave registers: biases / conditioning / previous state of unit `lane` (lanes < UPB)
+    const int my_unit = UPB * blk + (lane < UPB ? lane : 0);
+    const float4 bq = p.bh4[(my_unit >> 2) * 4 + (my_unit & 3)];
+    float4 gcq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float hold = 0.f;
+    const float fc_bias = wave == 0 ? (lane < 32 ? p.b_fc1[RPB * blk + row_local] : p.b_fc2[RPB * blk + row_local]) : 0.f;
+    ps_barrier();
+
+    bool dead = false;                                    // service wave: an exchange timed out
+    for (int t = 0; t < n; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        if (wave == 7) {
+            // ---- x_{t-1} from the 64 candidates of step t-1, then the cell update of the owned units
+            int x = NC / 2;
+            if (t > 0 && !dead) {
+                unsigned v[1];
+                u64 g = 0;
+                {   // candidates carry (tag << 8 | class) in the high word and the score in the low word
+                    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spins = 0;; ++spins) {
+                        g = ps_load(p.gc + lane);
+                        if (__all((unsigned)(g >> 40) == (unsigned)t)) break;
+                        if ((spins & 63) == 63) {
+                            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;
+                            if (late || __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                                if (late && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                dead = true;
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                (void)v;
+                float best = __uint_as_float((unsigned)g);
+                int cls = (int)((g >> 32) & 255u);
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {                 // first argmax: higher score, then lower class
+                    const float os = __shfl_xor(best, off);
+                    const int oc = __shfl_xor(cls, off);
+                    if (os > best || (os == best && oc < cls)) { best = os; cls = oc; }
+                }
+                x = cls;
+                if (blk == 0 && lane == 0 && !dead) {                    // network_vocoder.py:78 output: sample t-1
+                    if (p.wav) p.wav[t - 1] = p.mulaw_tab[x];
+                    if (p.mulaw) p.mulaw[t - 1] = x;
+                }
+            }
+            if (!dead) {
+                if (t % p.upsample == 0 && lane < UPB) {                 // next conditioning frame (once per hop)
+                    const int f = t / p.upsample < p.F ? t / p.upsample : p.F - 1;
+                    const float *gcp = p.Gcond + (size_t)f * 3 * Hr + my_unit;
+                    gcq = make_float4(gcp[0], gcp[Hr], gcp[2 * Hr], 0.f);
+                }
+                if (lane < UPB) {
+                    const float4 eq = gemb[x * UPB + lane];
+                    const bool first = t == 0;
+                    const float gr = first ? 0.f : gsum[lane], gz = first ? 0.f : gsum[UPB + lane], gn = first ? 0.f : gsum[2 * UPB + lane];
+                    const float r = sigmoidf_((eq.x + gcq.x) + (gr + bq.x));
+                    const float z = sigmoidf_((eq.y + gcq.y) + (gz + bq.y));
+                    const float nn = tanhf((eq.z + gcq.z) + r * (gn + bq.z));
+                    hold = (1.0f - z) * nn + z * hold;
+                    ps_store(p.gh + my_unit, ((u64)tag << 32) | __float_as_uint(hold));
+                }
+                // ---- gather h_t
+                unsigned hv[SW];
+                if (ps_sweep<SW>(p.gh, lane, tag, hv, p.abort_flag)) {
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) hbuf[ps_perm(lane + 64 * j)] = __uint_as_float(hv[j]);
+                } else dead = true;
+            }
+            if (dead) s_abort = 1;
+            ps_barrier();                                                // A: h_t in LDS
+            if (!dead) {
+                unsigned av[Hf / 64];
+                if (ps_sweep<Hf / 64>(p.ga, lane, tag, av, p.abort_flag)) {
+#pragma unroll
+                    for (int j = 0; j < Hf / 64; ++j) a1buf[ps_perm(lane + 64 * j)] = __uint_as_float(av[j]);
+                } else { dead = true; s_abort = 1; }
+            }
+            ps_barrier();                                                // B: a_t and W_hh h_t in LDS
+        } else if (wave == 0) {
+            float gum = 0.f;
+            if (lane >= 32 && (lane & 7) == 0) {                         // the draw's noise does not depend on the data
+                const int cls = RPB * blk + row_local;
+                const unsigned wd = philox_word((unsigned)t, p.utt, (unsigned)(cls >> 2), (unsigned)p.seed, (unsigned)(p.seed >> 32), cls & 3);
+                gum = -logf(-logf(((float)(wd >> 9) + 0.5f) * (1.0f / 8388608.0f)));
+            }
+            ps_barrier();                                                // A
+            if (s_abort == 0 && lane < 32) {
+                const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
+                float v = ps_combine(acc, lane);
+                v += fc_bias;
+                if ((lane & 7) == 0) ps_store(p.ga + RPB * blk + row_local, ((u64)tag << 32) | __float_as_uint(v > 0.f ? v : 0.f));
+            }
+            ps_barrier();                                                // B
+            if (s_abort == 0 && lane >= 32) {
+                float w2[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) w2[i] = w[i];
+                const float acc = ps_chain<4>(w2, (const float4 *)a1buf, kw, c0);
+                float v = ps_combine(acc, lane);
+                v += fc_bias;
+                float sc = v + gum;
+                int cls = RPB * blk + row_local;
+#pragma unroll
+                for (int off = 8; off < 32; off <<= 1) {                 // first max over the 4 classes (lanes 32, 40, 48, 56)
+                    const float os = __shfl_xor(sc, off);
+                    const int oc = __shfl_xor(cls, off);
+                    if (os > sc || (os == sc && oc < cls)) { sc = os; cls = oc; }
+                }
+                if (lane == 32) ps_store(p.gc + blk, ((u64)((tag << 8) | (unsigned)cls) << 32) | __float_as_uint(sc));
+            }
+        } else {
+            ps_barrier();                                                // A
+            if (s_abort == 0) {
+                const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
+                const float v = ps_combine(acc, lane);
+                if (gru_lane && (lane & 7) == 0) gsum[row_local] = v;
+            }
+            ps_barrier();                                                // B
+        }
+        if (s_abort != 0) break;                                         // read after barrier B: uniform for the workgroup
+    }
+    // ---- the last sample is still only candidates
+    if (wave == 7 && blk == 0 && n > 0 && s_abort == 0) {
+        u64 g = 0;
+        bool ok = true;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            g = ps_load(p.gc + lane);
+            if (__all((unsigned)(g >> 40) == (unsigned)n)) break;
+            if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
+                                       __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        float best = __uint_as_float((unsigned)g);
+        int cls = (int)((g >> 32) & 255u);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float os = __shfl_xor(best, off);
+            const int oc = __shfl_xor(cls, off);
+            if (os > best || (os == best && oc < cls)) { best = os; cls = oc; }
+        }
+        if (ok && lane == 0) {
+            if (p.wav) p.wav[n - 1] = p.mulaw_tab[cls];
+            if (p.mulaw) p.mulaw[n - 1] = cls;
+        }
+        if (!ok && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ void ar_advance_kernel(ArCall *c, int n) {
     c->t_base += n;
     if (c->hall && c->t_base - c->hall_t0 >= c->CH) c->hall_t0 += c->CH;      // next chunk of the teacher-forced scan
@@ -907,6 +1203,10 @@ struct vqcpc_vocoder {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf series, gi, out0, cond, gcond, hseq, len;
     DevBuf hall, a1c;                    // teacher-forced scan: h_t and fc1 outputs of one chunk
+    DevBuf px;                           // persistent single-utterance decoder: granules + abort flag
+    float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
+    int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
+    bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
@@ -941,9 +1241,10 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
                      v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh12, v->Wf_hh16, v->b_hh,
                      v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab, v->w_fc1, v->w_fc2};
     for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (v->w_hh) (void)hipFree(v->w_hh);
     if (v->Gemb4) (void)hipFree(v->Gemb4);
     if (v->bh4) (void)hipFree(v->bh4);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->px};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -998,6 +1299,7 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 16, Hr, 4, 0, 0, &v->Wf_fc1));
     TRY(build_wfrag(w->fc1_weight, Hr, w->Hf / 8, Hr, 4, 8, 0, &v->Wf_fc1h));
     TRY(build_wfrag(w->fc2_weight, w->Hf, w->n_cls / 16, w->Hf, 1, 0, 0, &v->Wf_fc2));
+    TRY(dcopy(&v->w_hh, w->ar_w_hh, (size_t)3 * Hr * Hr));
     TRY(dcopy(&v->w_fc1, w->fc1_weight, (size_t)w->Hf * Hr));
     TRY(dcopy(&v->w_fc2, w->fc2_weight, (size_t)w->n_cls * w->Hf));
     TRY(dcopy(&v->b_fc1, w->fc1_bias, w->Hf));
@@ -1063,6 +1365,11 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         return VQCPC_OK;
     }
     if (!strcmp(name, "two_groups")) { v->two_groups = value != 0; return VQCPC_OK; }
+    if (!strcmp(name, "persistent")) {
+        VQ_REQUIRE(value >= -1 && value <= 1, "persistent must be -1 (auto), 0 or 1");
+        v->persistent = value;
+        return VQCPC_OK;
+    }
     if (!strcmp(name, "tf_chunk_replays")) {
         VQ_REQUIRE(value >= 1 && value <= 64, "tf_chunk_replays must be in [1, 64]");
         v->tf_chunk_replays = value;
@@ -1077,8 +1384,22 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
     return VQCPC_ERR_INVALID;
 }
 
+// After the stream that carried a persistent decode has been synchronised: did an in-kernel exchange time out?
+static int persist_check(vqcpc_vocoder *v) {
+    if (!v->persist_pending) return VQCPC_OK;
+    v->persist_pending = false;
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpy(&flag, (char *)v->px.p + ((size_t)(v->d.Hr + v->d.Hf + PS_NB) * sizeof(u64)), sizeof flag, hipMemcpyDeviceToHost));
+    if (flag != 0) {
+        vq_set_error("persistent decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete)");
+        return VQCPC_ERR_HIP;
+    }
+    return VQCPC_OK;
+}
+
 extern "C" int vqcpc_vocoder_last_timing(vqcpc_vocoder *v, float *loop_ms, int *n_steps) {
     VQ_REQUIRE(v && loop_ms && n_steps, "vqcpc_vocoder_last_timing: null argument");
+    TRY(persist_check(v));
     HIP_TRY(hipEventElapsedTime(loop_ms, v->ev0, v->ev1));
     *n_steps = v->last_steps;
     return VQCPC_OK;
@@ -1243,6 +1564,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         HIP_TRY(hipMemcpyAsync(v->grp[g].cur.p, table[g].data(), (size_t)Spg * sizeof(ArSlot), hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipStreamSynchronize(s));     // host vectors above die with this frame
+    TRY(persist_check(v));
     const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
 
     const size_t rows = (size_t)B * T2;
@@ -1252,6 +1574,29 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     TRY(vq_gemm_chain(v->cond.as<float>(), dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)rows, 3 * Hr, dl, dl, s));
     if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
+
+    // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
+    if (v->persistent != 0 && B == 1 && !inputs && Hr == 896 && d.Hf == 256 && d.n_cls == 256 && lens[Bp] > 0 &&
+        lens[Bp] < (1 << 24)) {
+        const size_t ngr = (size_t)Hr + d.Hf + PS_NB;
+        TRY(v->px.reserve(ngr * sizeof(u64) + 16));
+        HIP_TRY(hipMemsetAsync(v->px.p, 0, ngr * sizeof(u64) + 16, s));
+        PersistP pp{};
+        pp.w_hh = v->w_hh; pp.w_fc1 = v->w_fc1; pp.b_fc1 = v->b_fc1; pp.w_fc2 = v->w_fc2; pp.b_fc2 = v->b_fc2;
+        pp.Gemb4 = v->Gemb4; pp.bh4 = v->bh4; pp.Gcond = v->gcond.as<float>(); pp.mulaw_tab = v->mulaw_tab;
+        pp.gh = v->px.as<u64>(); pp.ga = pp.gh + Hr; pp.gc = pp.ga + d.Hf;
+        pp.abort_flag = (unsigned *)(pp.gc + PS_NB);
+        pp.wav = wav; pp.mulaw = mulaw; pp.n_steps = lens[Bp]; pp.upsample = d.upsample_t; pp.F = T2;
+        pp.utt = utt[0]; pp.seed = seed;
+        HIP_TRY(hipEventRecord(v->ev0, s));
+        hipLaunchKernelGGL((ar_persist_kernel<14>), dim3(PS_NB), dim3(512), 0, s, pp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(v->ev1, s));
+        v->last_steps = lens[Bp];
+        v->have_last = false;              // no launch-per-step state to time
+        v->persist_pending = true;
+        return VQCPC_OK;
+    }
 
     ArCall calls[2];
     ArModel models[2];
