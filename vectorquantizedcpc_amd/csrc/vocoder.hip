@@ -898,7 +898,8 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
     __shared__ __attribute__((aligned(16))) float hbuf[Hr];            // h_t, ps_perm order
     __shared__ __attribute__((aligned(16))) float a1buf[Hf];           // a_t, ps_perm order
     __shared__ float gsum[3 * UPB];                                     // W_hh h_{t-1} of the owned rows [gate][unit]
-    __shared__ int s_abort;
+    __shared__ int s_abort[2];                                          // [t & 1]: written by the service wave during step t only, so a
+                                                                        // wave still reading step t-1's verdict never sees step t's
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
     const int n = p.n_steps;
 
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
         const int cls = e / UPB, unit = UPB * blk + (e - cls * UPB);
         gemb[e] = p.Gemb4[((size_t)cls * (Hr >> 2) + (unit >> 2)) * 4 + (unit & 3)];
     }
-    if (tid == 0) s_abort = 0;
+    if (tid == 0) { s_abort[0] = 0; s_abort[1] = 0; }
     // service-wave registers: biases / conditioning / previous state of unit `lane` (lanes < UPB)
     const int my_unit = UPB * blk + (lane < UPB ? lane : 0);
     const float4 bq = p.bh4[(my_unit >> 2) * 4 + (my_unit & 3)];
@@ -937,8 +938,10 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
     ps_barrier();
 
     bool dead = false;                                    // service wave: an exchange timed out
+    bool aborted = false;
     for (int t = 0; t < n; ++t) {
         const unsigned tag = (unsigned)t + 1u;
+        volatile int *ab = &s_abort[t & 1];
         if (wave == 7) {
             // ---- x_{t-1} from the 64 candidates of step t-1, then the cell update of the owned units
             int x = NC / 2;
@@ -999,14 +1002,14 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     for (int j = 0; j < SW; ++j) hbuf[ps_perm(lane + 64 * j)] = __uint_as_float(hv[j]);
                 } else dead = true;
             }
-            if (dead) s_abort = 1;
+            if (dead) *ab = 1;
             ps_barrier();                                                // A: h_t in LDS
             if (!dead) {
                 unsigned av[Hf / 64];
                 if (ps_sweep<Hf / 64>(p.ga, lane, tag, av, p.abort_flag)) {
 #pragma unroll
                     for (int j = 0; j < Hf / 64; ++j) a1buf[ps_perm(lane + 64 * j)] = __uint_as_float(av[j]);
-                } else { dead = true; s_abort = 1; }
+                } else { dead = true; *ab = 1; }
             }
             ps_barrier();                                                // B: a_t and W_hh h_t in LDS
         } else if (wave == 0) {
@@ -1017,14 +1020,14 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 gum = -logf(-logf(((float)(wd >> 9) + 0.5f) * (1.0f / 8388608.0f)));
             }
             ps_barrier();                                                // A
-            if (s_abort == 0 && lane < 32) {
+            if (*ab == 0 && lane < 32) {
                 const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
                 float v = ps_combine(acc, lane);
                 v += fc_bias;
                 if ((lane & 7) == 0) ps_store(p.ga + RPB * blk + row_local, ((u64)tag << 32) | __float_as_uint(v > 0.f ? v : 0.f));
             }
             ps_barrier();                                                // B
-            if (s_abort == 0 && lane >= 32) {
+            if (*ab == 0 && lane >= 32) {
                 float w2[32];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) w2[i] = w[i];
@@ -1043,17 +1046,17 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
             }
         } else {
             ps_barrier();                                                // A
-            if (s_abort == 0) {
+            if (*ab == 0) {
                 const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
                 const float v = ps_combine(acc, lane);
                 if (gru_lane && (lane & 7) == 0) gsum[row_local] = v;
             }
             ps_barrier();                                                // B
         }
-        if (s_abort != 0) break;                                         // read after barrier B: uniform for the workgroup
+        if (*ab != 0) { aborted = true; break; }                         // read after barrier B: uniform for the workgroup
     }
     // ---- the last sample is still only candidates
-    if (wave == 7 && blk == 0 && n > 0 && s_abort == 0) {
+    if (wave == 7 && blk == 0 && n > 0 && !aborted) {
         u64 g = 0;
         bool ok = true;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
