@@ -96,9 +96,11 @@ void vqcpc_encoder_destroy(vqcpc_encoder *enc);
 int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int conv_mode,
                          float *z_q, float *c, int64_t *idx, float *z_pre, void *stream);
 
-/* Encoder options.  fused: -1 (default) = the one-launch fused front end (conv, LayerNorms, FC stack and VQ search for 16
- * rows per workgroup, activations resident in LDS) whenever the layout supports it (4 * in_channels <= 512), 0 = the
- * layered kernels (one launch per module of model.py:43-55), 1 = fused or error.  Both paths produce the same bits. */
+/* Encoder options.  fused: which schedule of the front end runs (all produce the same bits): 1 = ONE launch, conv +
+ * LayerNorms + FC stack + VQ search for 16 whole rows per workgroup with the activations resident in LDS; 2 = six
+ * column-split launches (one per Linear, LayerNorm applied on load, VQ in the last) for calls too small to fill the chip
+ * with whole-row workgroups; 0 = the layered kernels, one launch per module of model.py:43-55; -1 (default) = 2 for calls
+ * of up to `split_max_tiles` (default 64) 16-row tiles, else 1; 0 when 4 * in_channels > 512. */
 int vqcpc_encoder_set_option(vqcpc_encoder *enc, const char *name, int value);
 
 /* Activations after one stage of the front end for the same inputs as encode() -- the analogue

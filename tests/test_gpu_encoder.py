@@ -161,21 +161,23 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("name", ["c2_init", "odd_2x33", "c1_init", "c2_random_data"])
 def test_layered_and_fused_front_ends_same_bits(name, golden_dir):
-    """The one-launch fused front end (default) and the layered kernels (one launch per module) are two schedules of the
-    same rounding sequence: every stage, z and the indices carry the same bits, and both equal the reference's SHAs."""
+    """The one-launch fused front end (1), the six column-split launches for small calls (2) and the layered kernels
+    (0, one launch per module) are three schedules of the same rounding sequence: every stage, z, z_pre and the indices
+    carry the same bits, and they equal the reference's SHAs.  (Default: 2 up to 64 row tiles, else 1.)"""
     g, enc, sd, mel = load_case(name, golden_dir)
     melc = mel.cuda()
     outs = {}
     try:
-        for fused in (1, 0):
+        for fused in (1, 2, 0):
             enc.set_option("fused", fused)
             z, c, idx = enc.encode(melc)
             stages = [enc.stage(melc, s) for s in range(11)]
             outs[fused] = (z, idx, stages)
     finally:
         enc.set_option("fused", -1)
-    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][1], outs[1][1])
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[2][0].view(torch.int32), outs[1][0].view(torch.int32))
     for s in range(11):
         assert torch.equal(outs[0][2][s].view(torch.int32), outs[1][2][s].view(torch.int32)), s
     assert sha(outs[1][0].cpu().numpy()) == str(g["sha_z"])

@@ -732,6 +732,136 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
     vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1);
 }
 
+// ------------------------------------------------------------------------------------------
+// Small calls (a single utterance: BASELINE configs[0], encode.py:44-46): too few 16-row tiles to fill the chip with
+// whole-row workgroups, and each of those would still stream all 5 MB of weights.  Here the columns are split over
+// 8 workgroups per row tile (4 waves x one 16-column tile) and one launch covers one Linear:
+//   launch 0: im2col + conv                                -> raw rows
+//   launch l = 1..4: LayerNorm_{l-1} + ReLU of the raw rows ON LOAD (each of the 8 column workgroups repeats it for
+//                    its 16 rows: 16 x 512 elements, nothing next to the launch boundary it saves) + Linear_l -> raw rows
+//   launch 5: LayerNorm_4 + ReLU on load + encoder.14 + VQ search (one workgroup per row tile, as the fused tail)
+// Six launches instead of fourteen, same chains, same bits.  The K blocks of a chain fold are independent
+// zero-started chains, so a wave runs them interleaved (NBLK accumulators) instead of one dependent MFMA sequence.
+// ------------------------------------------------------------------------------------------
+template <int NBLK>
+__device__ __forceinline__ f32x4 rows16_gemm_blocks(const float *tile, const float4 *__restrict__ Wf, int ct, int kcq,
+                                                    const float *__restrict__ bias, int lane) {
+    const int nq = NBLK * kcq;
+    const float4 *wp = Wf + ((size_t)ct * nq) * 64 + lane;
+    const float *arow = tile + (lane & 15) * FE_LD + (lane >> 4);
+    f32x4 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 fr[2][NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) fr[0][b] = wp[(size_t)(b * kcq) * 64];
+    for (int s = 0; s < kcq; s += 2) {                                 // kcq is even (4, 16 or 20)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int sn = s + u + 1 < kcq ? s + u + 1 : s + u;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) fr[u ^ 1][b] = wp[(size_t)(b * kcq + sn) * 64];
+            float a[NBLK][4];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[b][c] = arow[16 * (b * kcq + s + u) + 4 * c];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][0], fr[u][b].x, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][1], fr[u][b].y, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][2], fr[u][b].z, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][3], fr[u][b].w, acc[b], 0, 0, 0);
+        }
+    }
+    const float bv = bias ? bias[16 * ct + (lane & 15)] : 0.f;
+    f32x4 tot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        tot[r] = bias ? bv + acc[0][r] : acc[0][r];
+#pragma unroll
+        for (int b = 1; b < NBLK; ++b) tot[r] = tot[r] + acc[b][r];
+    }
+    return tot;
+}
+
+// layer: 0 conv, 1..4 Linear l (LayerNorm l-1 on load), 5 encoder.14 + VQ (LayerNorm 4 on load)
+__global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, const float *__restrict__ in, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
+    __shared__ VqSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = blockIdx.x, r0 = blockIdx.y * 16;
+    if (layer == 0) {
+        const int K0 = 4 * p.C;
+        for (int e = tid; e < 16 * K0; e += 256) {
+            const int i = e & 15, kidx = e >> 4, m = r0 + i;
+            int c, tap;
+            if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
+            else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
+            float v = 0.f;
+            if (m < p.N) {
+                const int b = m / p.To, tt = m - b * p.To, ti = 2 * tt + tap - 1;
+                if (ti >= 0 && ti < p.T) v = p.mel[((size_t)b * p.C + c) * p.T + ti];
+            }
+            tile[i * FE_LD + kidx] = v;
+        }
+        __syncthreads();
+        const int ct = 4 * cg + wave, nq = K0 / 16;
+        f32x4 tot;
+        if (p.conv_mode == 1) tot = rows16_gemm_blocks<1>(tile, p.conv_f, ct, nq, nullptr, lane);
+        else if (nq == 20) tot = rows16_gemm_blocks<5>(tile, p.conv_f, ct, 4, nullptr, lane);
+        else {                                                            // other channel counts: the generic fold
+            f32x4 t1[1];
+            rows16_gemm<1>(tile, p.conv_f, ct, nq, 4, nullptr, t1, lane);
+            tot = t1[0];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = r0 + 4 * (lane >> 4) + r;
+            if (m < p.N) out[(size_t)m * 512 + 16 * ct + (lane & 15)] = tot[r];
+        }
+        return;
+    }
+    // raw rows of the previous Linear / conv -> LDS, LayerNorm + ReLU in place
+    for (int e = tid; e < 16 * 128; e += 256) {
+        const int row = e >> 7, c4 = e & 127;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < p.N) v = ((const float4 *)in)[(size_t)(r0 + row) * 128 + c4];
+        float *d = tile + row * FE_LD + 4 * c4;
+        *(float2 *)d = make_float2(v.x, v.y);
+        *(float2 *)(d + 2) = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    rows16_layernorm(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
+    __syncthreads();
+    if (layer < 5) {
+        const int ct = 4 * cg + wave;
+        const f32x4 tot = rows16_gemm_blocks<2>(tile, p.fc_f[layer - 1], ct, 16, nullptr, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = r0 + 4 * (lane >> 4) + r;
+            if (m < p.N) out[(size_t)m * 512 + 16 * ct + (lane & 15)] = tot[r];
+        }
+        return;
+    }
+    const int tpw = p.n_emb / 64, t0 = wave * tpw;
+    float4 f0[4], f1[4];
+    vq_load_tile(p.Ef, t0, lane, f0);
+    vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
+    const f32x4 zt = rows16_gemm_blocks<2>(tile, p.out_f, wave, 16, p.out_b, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
+        sm.xs[row][col] = zt[r];
+        if (p.z_pre && r0 + row < p.N) p.z_pre[(size_t)(r0 + row) * 64 + col] = zt[r];
+    }
+    __syncthreads();
+    if (tid < 16) sm.x2s[tid] = r0 + tid < p.N ? sumsq64(&sm.xs[tid][0]) : 0.f;
+    __syncthreads();
+    vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1);
+}
+
 // Eval-branch statistics of VQEmbeddingEMA.forward (model.py:147-153): deterministic two-level
 // reductions (per-block partials, then one block in fixed order).
 __global__ __launch_bounds__(256) void vq_stats_partial_kernel(const float *__restrict__ x, const float *__restrict__ q,
@@ -806,7 +936,9 @@ struct vqcpc_encoder {
     DevBuf bufA, bufB, zpre, stats;
     // fused front end (enc_fused_kernel): weights in 16x16x4 fragment order
     float4 *conv_f[2] = {nullptr, nullptr}, *fc_f[4] = {}, *out_f = nullptr;
-    int fused = -1;                      // -1 auto (fused when the layout supports it), 0 layered kernels, 1 fused
+    int fused = -1;                      // -1 auto (split below split_max_tiles row tiles, else fused), 0 layered kernels,
+                                         // 1 one-launch fused kernel, 2 six-launch column-split kernels
+    int split_max_tiles = 64;            // auto: calls of up to this many 16-row tiles take the column-split launches
 };
 
 static int dev_copy(float **dst, const float *src, size_t n) {
@@ -950,7 +1082,21 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
     p.Ef = (const float4 *)e->cbfrag; p.E = e->codebook; p.e2 = e->e2; p.n_emb = e->n_emb;
     p.z_pre = z_pre; p.z_q = z_q; p.idx = idx; p.stage_out = stage_out; p.stage = stage;
     p.eps = 1e-5f; p.lnc = e->lnc;
-    hipLaunchKernelGGL(enc_fused_kernel, dim3((N + 15) / 16), dim3(256), 0, s, p);
+    const int ntiles = (N + 15) / 16;
+    const bool split = stage < 0 && (e->fused == 2 || (e->fused != 1 && ntiles <= e->split_max_tiles));
+    if (split) {                                          // small call: six column-split launches (enc_split_kernel)
+        TRY(e->bufA.reserve((size_t)N * 512 * sizeof(float)));
+        TRY(e->bufB.reserve((size_t)N * 512 * sizeof(float)));
+        float *a = e->bufA.as<float>(), *b = e->bufB.as<float>();
+        hipLaunchKernelGGL(enc_split_kernel, dim3(8, ntiles), dim3(256), 0, s, p, 0, (const float *)nullptr, a);
+        for (int l = 1; l <= 4; ++l) {
+            hipLaunchKernelGGL(enc_split_kernel, dim3(8, ntiles), dim3(256), 0, s, p, l, (const float *)a, b);
+            float *t = a; a = b; b = t;
+        }
+        hipLaunchKernelGGL(enc_split_kernel, dim3(1, ntiles), dim3(256), 0, s, p, 5, (const float *)a, (float *)nullptr);
+    } else {
+        hipLaunchKernelGGL(enc_fused_kernel, dim3(ntiles), dim3(256), 0, s, p);
+    }
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
 }
@@ -958,9 +1104,14 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
 extern "C" int vqcpc_encoder_set_option(vqcpc_encoder *e, const char *name, int value) {
     VQ_REQUIRE(e && name, "vqcpc_encoder_set_option: null argument");
     if (!strcmp(name, "fused")) {
-        VQ_REQUIRE(value >= -1 && value <= 1, "fused must be -1 (auto), 0 or 1");
-        VQ_REQUIRE(value != 1 || e->conv_f[0], "fused front end needs 4 * in_channels <= 512");
+        VQ_REQUIRE(value >= -1 && value <= 2, "fused must be -1 (auto), 0, 1 or 2");
+        VQ_REQUIRE(value < 1 || e->conv_f[0], "fused front end needs 4 * in_channels <= 512");
         e->fused = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "split_max_tiles")) {
+        VQ_REQUIRE(value >= 0, "split_max_tiles must be >= 0");
+        e->split_max_tiles = value;
         return VQCPC_OK;
     }
     vq_set_error("unknown option %s", name);
