@@ -14,10 +14,13 @@
  *    before the call returns.
  *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream).  No call synchronises the device except where stated: the *_create calls do
- *    (once); vqcpc_vocoder_generate / _logits, vqcpc_melfront_run and vqcpc_loudness_* synchronise `stream`
- *    while they upload host-built tables (lengths, decode-slot schedule) BEFORE enqueuing
- *    their kernels, and return with the work still in flight; vqcpc_vocoder_kernel_times
- *    is a measurement call and returns after its launches have finished.
+ *    (once); vqcpc_melfront_run and vqcpc_loudness_* synchronise `stream` once while they upload
+ *    host-built length tables BEFORE enqueuing their kernels, and return with the work still in
+ *    flight; vqcpc_vocoder_kernel_times is a measurement call and returns after its launches have
+ *    finished.  vqcpc_vocoder_generate / _logits do NOT synchronise the stream: their host-built
+ *    tables (lengths, decode-slot schedule, call records) go through a pinned staging arena owned by
+ *    the handle, and a call waits only for the event behind the PREVIOUS call's uploads before it
+ *    reuses that arena.
  *  - Return 0 on success, a negative vqcpc_status otherwise; never throws.
  *    vqcpc_last_error() returns a thread-local message for the last failure.
  *  - One handle per device; a handle is not thread-safe; distinct handles are independent.
@@ -178,7 +181,8 @@ int vqcpc_vocoder_generate(vqcpc_vocoder *voc, const int64_t *idx, const int64_t
 
 /* Replaces Vocoder.forward (network_vocoder.py:41-67; caller vocoder.py:62): teacher-forced
  * energies.  x DEVICE (B, Ts) int64 mu-law input samples, Ts <= 2*upsample_t*Tc;
- * logits DEVICE (B, Ts, n_cls) fp32. */
+ * logits DEVICE (B, Ts, n_cls) fp32.  Runs as a fused scan: with x given, only the GRU step is serial (one launch per
+ * sample that also stores h_t); fc1 + ReLU and fc2 run as two batched GEMMs per chunk of steps. */
 int vqcpc_vocoder_logits(vqcpc_vocoder *voc, const int64_t *x, const int64_t *idx,
                          const int64_t *speaker, int B, int Tc, int Ts, float *logits,
                          void *stream);
@@ -187,7 +191,13 @@ int vqcpc_vocoder_logits(vqcpc_vocoder *voc, const int64_t *x, const int64_t *id
 int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
                             int B, int Tc, float *cond, void *stream);
 
-/* Decode-loop options.  use_graph: replay the per-sample kernels from a captured hipGraph
+/* Decode-loop options.  persistent: -1 / 1 (default) = a call on ONE utterance (BASELINE configs[2]) runs on the
+ * persistent decoder -- 64 workgroups resident for the whole call, all weights in registers, the three all-to-all
+ * mixes of a sample step exchanged in-kernel -- when the dimensions are the reference's (size_h_rnn 896, size_h_fc 256);
+ * 0 = always the launch-per-step kernels.  Both produce the same bits.  If an in-kernel exchange ever times out (1 s),
+ * every workgroup leaves and the NEXT call on the handle (or vqcpc_vocoder_last_timing) returns VQCPC_ERR_HIP.
+ * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
+ * use_graph: replay the per-sample kernels from a captured hipGraph
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
  * slots: continuous batching -- decode with this many slots, each running utterances back to back
  * (0 = one slot per utterance).  big_min_tiles: utterance tiles (of 16) from which the LDS-staged

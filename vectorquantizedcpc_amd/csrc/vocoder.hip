@@ -817,7 +817,7 @@ struct PersistP {
     const float *Gcond;               // [F][3Hr] conditioning rows of this utterance (W_ih[:, de:] cond + b_ih)
     const float *mulaw_tab;
     u64 *gh, *ga, *gc;                // granules: [Hr] h_t, [Hf] a_t, [PS_NB] candidates
-    unsigned *abort_flag;
+    unsigned *abort_flag;             // pinned HOST memory (system-scope accesses): the host reads it without a HIP call
     float *wav; int64_t *mulaw;
     int n_steps, upsample, F;
     unsigned utt; u64 seed;
@@ -882,8 +882,8 @@ __device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, unsigned tag, u
         if (__all(ok)) return true;
         if ((spins & 63) == 63) {
             const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;          // 1 s at 100 MHz
-            if (late || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                if (late && lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (late || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                if (late && lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return false;
             }
         }
@@ -955,8 +955,8 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                         if (__all((unsigned)(g >> 40) == (unsigned)t)) break;
                         if ((spins & 63) == 63) {
                             const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;
-                            if (late || __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                                if (late && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (late || __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                                if (late && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 dead = true;
                                 break;
                             }
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
             g = ps_load(p.gc + lane);
             if (__all((unsigned)(g >> 40) == (unsigned)n)) break;
             if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
-                                       __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
+                                       __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         float best = __uint_as_float((unsigned)g);
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
             if (p.wav) p.wav[n - 1] = p.mulaw_tab[cls];
             if (p.mulaw) p.mulaw[n - 1] = cls;
         }
-        if (!ok && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1180,6 +1180,45 @@ __global__ void copy_submatrix_kernel(const float *__restrict__ src, int ld, int
     dst[i] = src[(size_t)r * ld + col0 + cidx];
 }
 
+// Pinned staging arena for host-built tables (lengths, decode-slot schedule, call records): the tables are copied in
+// and uploaded from there with hipMemcpyAsync, so a decode call never synchronises the caller's stream ("no
+// hidden sync").  The arena is reused by the next call only after the event recorded behind this call's uploads.
+struct HostStage {
+    char *p = nullptr;
+    size_t cap = 0, used = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int begin(size_t need) {
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (pending) { HIP_TRY(hipEventSynchronize(ev)); pending = false; }       // the PREVIOUS call's uploads only
+        if (need > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = need + need / 2 + 4096;
+            HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+            cap = want;
+        }
+        used = 0;
+        return VQCPC_OK;
+    }
+    int upload(void *dst, const void *src, size_t n, hipStream_t s) {
+        const size_t at = (used + 15) & ~(size_t)15;
+        VQ_REQUIRE(at + n <= cap, "host staging arena too small (%zu + %zu > %zu)", at, n, cap);
+        memcpy(p + at, src, n);
+        used = at + n;
+        HIP_TRY(hipMemcpyAsync(dst, p + at, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(ev, s));
+        pending = true;
+        return VQCPC_OK;
+    }
+    void release() {
+        if (pending && ev) (void)hipEventSynchronize(ev);
+        if (p) (void)hipHostFree(p);
+        if (ev) (void)hipEventDestroy(ev);
+        p = nullptr; ev = nullptr; cap = 0; pending = false;
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
@@ -1206,7 +1245,9 @@ struct vqcpc_vocoder {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf series, gi, out0, cond, gcond, hseq, len;
     DevBuf hall, a1c;                    // teacher-forced scan: h_t and fc1 outputs of one chunk
-    DevBuf px;                           // persistent single-utterance decoder: granules + abort flag
+    DevBuf px;                           // persistent single-utterance decoder: granules
+    unsigned *abort_host = nullptr;      // its abort flag: pinned host memory the kernel writes and the host reads without a HIP call
+    HostStage stage;
     float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
     int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
     bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
@@ -1244,6 +1285,8 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
                      v->p_bhh[1], v->p_wf[0], v->p_wf[1], v->w_cond, v->b_ih, v->Gemb, v->Wf_hh12, v->Wf_hh16, v->b_hh,
                      v->Wf_fc1, v->Wf_fc1h, v->b_fc1, v->Wf_fc2, v->b_fc2, v->mulaw_tab, v->w_fc1, v->w_fc2};
     for (float *p : ptrs) if (p) (void)hipFree(p);
+    v->stage.release();
+    if (v->abort_host) (void)hipHostFree(v->abort_host);
     if (v->w_hh) (void)hipFree(v->w_hh);
     if (v->Gemb4) (void)hipFree(v->Gemb4);
     if (v->bh4) (void)hipFree(v->bh4);
@@ -1317,6 +1360,8 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     HIP_TRY(hipMalloc((void **)&v->mulaw_tab, tab.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(v->mulaw_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     for (auto &g : v->grp) HIP_TRY(hipMalloc((void **)&g.call, sizeof(ArCall)));
+    HIP_TRY(hipHostMalloc((void **)&v->abort_host, 64, hipHostMallocMapped));
+    *v->abort_host = 0u;
     HIP_TRY(hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
@@ -1390,10 +1435,10 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
 // After the stream that carried a persistent decode has been synchronised: did an in-kernel exchange time out?
 static int persist_check(vqcpc_vocoder *v) {
     if (!v->persist_pending) return VQCPC_OK;
-    v->persist_pending = false;
-    unsigned flag = 0;
-    HIP_TRY(hipMemcpy(&flag, (char *)v->px.p + ((size_t)(v->d.Hr + v->d.Hf + PS_NB) * sizeof(u64)), sizeof flag, hipMemcpyDeviceToHost));
+    const unsigned flag = *(volatile unsigned *)v->abort_host;        // written by the kernel on a timeout; no HIP call
     if (flag != 0) {
+        v->persist_pending = false;
+        *(volatile unsigned *)v->abort_host = 0u;
         vq_set_error("persistent decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete)");
         return VQCPC_ERR_HIP;
     }
@@ -1546,8 +1591,8 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     const int n_grp = split ? 2 : 1;
     const int tiles[2] = {split ? (nbt + 1) / 2 : nbt, split ? nbt / 2 : 0};
     const int slot0[2] = {0, tiles[0] * 16};
+    TRY(persist_check(v));                // did an earlier persistent decode report a timeout?
     TRY(v->len.reserve(lens.size() * sizeof(int)));
-    HIP_TRY(hipMemcpyAsync(v->len.p, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, s));
     std::vector<ArSlot> table[2];
     int rep[2] = {0, 0}, gmax[2] = {0, 0};
     for (int g = 0; g < n_grp; ++g) {
@@ -1562,12 +1607,16 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
                 table[g][(size_t)r * Spg + (sg.slot - slot0[g])] = ArSlot{sg.row, sg.t0, sg.len, utt[sg.row]};
         }
         TRY(v->grp[g].slot_tab.reserve(table[g].size() * sizeof(ArSlot)));
-        HIP_TRY(hipMemcpyAsync(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), hipMemcpyHostToDevice, s));
         TRY(v->grp[g].cur.reserve((size_t)Spg * sizeof(ArSlot)));
-        HIP_TRY(hipMemcpyAsync(v->grp[g].cur.p, table[g].data(), (size_t)Spg * sizeof(ArSlot), hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(hipStreamSynchronize(s));     // host vectors above die with this frame
-    TRY(persist_check(v));
+    // upload through the pinned arena: no synchronisation of the caller's stream
+    TRY(v->stage.begin(lens.size() * sizeof(int) + (table[0].size() + table[1].size()) * sizeof(ArSlot) +
+                       (size_t)(tiles[0] + tiles[1]) * 16 * sizeof(ArSlot) + 2 * sizeof(ArCall) + 256));
+    TRY(v->stage.upload(v->len.p, lens.data(), lens.size() * sizeof(int), s));
+    for (int g = 0; g < n_grp; ++g) {
+        TRY(v->stage.upload(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), s));
+        TRY(v->stage.upload(v->grp[g].cur.p, table[g].data(), (size_t)tiles[g] * 16 * sizeof(ArSlot), s));
+    }
     const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
 
     const size_t rows = (size_t)B * T2;
@@ -1582,13 +1631,15 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     if (v->persistent != 0 && B == 1 && !inputs && Hr == 896 && d.Hf == 256 && d.n_cls == 256 && lens[Bp] > 0 &&
         lens[Bp] < (1 << 24)) {
         const size_t ngr = (size_t)Hr + d.Hf + PS_NB;
-        TRY(v->px.reserve(ngr * sizeof(u64) + 16));
-        HIP_TRY(hipMemsetAsync(v->px.p, 0, ngr * sizeof(u64) + 16, s));
+        TRY(v->px.reserve(ngr * sizeof(u64)));
+        HIP_TRY(hipMemsetAsync(v->px.p, 0, ngr * sizeof(u64), s));
+        unsigned *abort_dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev, v->abort_host, 0));
         PersistP pp{};
         pp.w_hh = v->w_hh; pp.w_fc1 = v->w_fc1; pp.b_fc1 = v->b_fc1; pp.w_fc2 = v->w_fc2; pp.b_fc2 = v->b_fc2;
         pp.Gemb4 = v->Gemb4; pp.bh4 = v->bh4; pp.Gcond = v->gcond.as<float>(); pp.mulaw_tab = v->mulaw_tab;
         pp.gh = v->px.as<u64>(); pp.ga = pp.gh + Hr; pp.gc = pp.ga + d.Hf;
-        pp.abort_flag = (unsigned *)(pp.gc + PS_NB);
+        pp.abort_flag = abort_dev;
         pp.wav = wav; pp.mulaw = mulaw; pp.n_steps = lens[Bp]; pp.upsample = d.upsample_t; pp.F = T2;
         pp.utt = utt[0]; pp.seed = seed;
         HIP_TRY(hipEventRecord(v->ev0, s));
@@ -1627,7 +1678,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
             c.hall = v->hall.as<float>(); c.hall_t0 = 0;
             c.logits = nullptr;                       // written by the chunk GEMMs, not by ar_fc2_kernel
         }
-        HIP_TRY(hipMemcpyAsync(G.call, &c, sizeof c, hipMemcpyHostToDevice, s));
+        TRY(v->stage.upload(G.call, &c, sizeof c, s));
         ArModel &m = models[g];
         m = ArModel{};
         m.Wf_hh12 = v->Wf_hh12; m.Wf_hh16 = v->Wf_hh16; m.bh4 = v->bh4; m.Gemb4 = v->Gemb4; m.Gemb = v->Gemb; m.Wf_fc1 = v->Wf_fc1; m.Wf_fc1h = v->Wf_fc1h; m.b_fc1 = v->b_fc1;
@@ -1641,7 +1692,6 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         m.lead6 = n_grp == 2 && nb <= 2;
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
-    HIP_TRY(hipStreamSynchronize(s));     // calls[] is a stack-lifetime host buffer
     for (int g = 0; g < n_grp; ++g)       // replay 0's slot row and Gcond rows
         hipLaunchKernelGGL(ar_next_row_kernel, dim3(tiles[g] * 16), dim3(256), 0, s, models[g], (const ArCall *)v->grp[g].call);
 
