@@ -106,6 +106,37 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class WeightSlots:
+    """The tensors behind a fixed list of ``state_dict()`` names, re-read per call WITHOUT ``state_dict()`` (which
+    costs ~70 us on these modules -- more than a small kernel call): each name is resolved once to the
+    ``_parameters`` / ``_buffers`` dict that holds it, so a later ``.to()``, ``load_state_dict`` or assignment is
+    still seen.  ``key()`` = ((data_ptr, _version), ...), what the native handles are cached on."""
+
+    def __init__(self, module, names):
+        self.names = list(names)
+        self.slots = []
+        for name in self.names:
+            *path, leaf = name.split(".")
+            mod = module
+            for part in path:
+                mod = mod._modules[part]
+            self.slots.append((mod._parameters if leaf in mod._parameters else mod._buffers, leaf))
+
+    def tensors(self):
+        return [d[k] for d, k in self.slots]
+
+    @staticmethod
+    def key(tensors):
+        return tuple([(t.data_ptr(), t._version) for t in tensors])
+
+
+def device_guard(dev):
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager costs ~5 us)."""
+    import contextlib
+    import torch
+    return contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def require_same_device(t, ref, what: str):
     """torch's 'expected all tensors to be on the same device' for an input next to the module's weights."""
     if t.device != ref.device:

@@ -113,21 +113,25 @@ class Encoder(nn.Module):
         self._handle_key = None
 
     # ------------------------------------------------------------------ native handle
-    def _weights(self):
-        sd = {k: v for k, v in self.state_dict().items()}
-        return [sd[k] for k in sd if k not in ("codebook.ema_count", "codebook.ema_weight")]
+    _WEIGHT_NAMES = (["conv.weight"] + [f"encoder.{n}.{k}" for n in (0, 3, 6, 9, 12) for k in ("weight", "bias")] +
+                     [f"encoder.{n}.weight" for n in (2, 5, 8, 11)] + ["encoder.14.weight", "encoder.14.bias",
+                      "codebook.embedding", "rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0"])
 
     def _native(self):
-        ws = self._weights()
+        slots = self.__dict__.get("_slots")
+        if slots is None:
+            slots = self.__dict__["_slots"] = _lib.WeightSlots(self, self._WEIGHT_NAMES)
+        ws = slots.tensors()
+        key = _lib.WeightSlots.key(ws)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
         for w in ws:
             _lib.require_cuda(w, "Encoder parameter")
             if w.dtype != torch.float32:
                 raise RuntimeError("Encoder: parameters must be float32")
-        key = tuple((w.data_ptr(), w._version) for w in ws) + (ws[0].device.index,)
-        if self._handle is not None and key == self._handle_key:
-            return self._handle
+            _lib.require_same_device(w, ws[0], "a parameter")
         self._release()
-        sd = self.state_dict()
+        sd = dict(zip(slots.names, ws))
         keep = []
 
         def p(name):
@@ -163,6 +167,7 @@ class Encoder(nn.Module):
     def __getstate__(self):                             # the native handle is per object: a copy builds its own
         d = self.__dict__.copy()
         d["_handle"], d["_handle_key"] = None, None
+        d.pop("_slots", None)
         return d
 
     def __setstate__(self, state):
@@ -188,28 +193,30 @@ class Encoder(nn.Module):
             pass
 
     # ------------------------------------------------------------------ reference surface
-    def _encode_native(self, mel: Tensor, want_c: bool, conv_mode: int = 0):
+    def _encode_native(self, mel: Tensor, want_c: bool, conv_mode: int = 0, want_pre: bool = False):
         _lib.require_cuda(mel, "mel")
         if mel.dim() != 3 or mel.size(1) != self.conf.in_channels:
             raise RuntimeError(f"expected mel of shape (B, {self.conf.in_channels}, T), got {tuple(mel.shape)}")
         if mel.size(2) < 2:
             raise RuntimeError("Conv1d(k=4, s=2, p=1) needs at least 2 mel frames")
         _lib.require_same_device(mel, self.conv.weight, "mel")
-        mel = mel.detach().to(torch.float32).contiguous()
+        if mel.dtype != torch.float32 or not mel.is_contiguous() or mel.requires_grad:
+            mel = mel.detach().to(torch.float32).contiguous()
         B, _, T = mel.shape
         To = (T - 2) // 2 + 1                        # nn.Conv1d(k4, s2, p1) output length (model.py:43)
         h = self._native()
         dev = mel.device
+        last = self.encoder._modules["14"]
+        hooks = last._forward_hooks
         z = torch.empty(B, To, self.conf.z_dim, device=dev)
-        z_pre = torch.empty_like(z)
+        z_pre = torch.empty_like(z) if (want_pre or hooks) else None       # pre-VQ rows only when somebody reads them
         idx = torch.empty(B, To, dtype=torch.int64, device=dev)
         c = torch.empty(B, To, self.conf.c_dim, device=dev) if want_c else None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(_lib.load().vqcpc_encoder_encode(
                 h, mel.data_ptr(), B, T, conv_mode, z.data_ptr(), c.data_ptr() if want_c else None,
-                idx.data_ptr(), z_pre.data_ptr(), _lib.current_stream()))
-        last = self.encoder[-1]
-        for hook in list(last._forward_hooks.values()):     # encode.py:34-40 captures the pre-VQ activations
+                idx.data_ptr(), z_pre.data_ptr() if z_pre is not None else None, _lib.current_stream()))
+        for hook in list(hooks.values()):                   # encode.py:34-40 captures the pre-VQ activations
             hook(last, (None,), z_pre)
         return z, c, idx, z_pre
 
@@ -244,7 +251,7 @@ class Encoder(nn.Module):
             raise NotImplementedError("vectorquantizedcpc_amd.Encoder implements the inference path; "
                                       "call .eval() (the EMA/straight-through training branch, model.py:136-145, is out of scope)")
         with torch.no_grad():
-            zq, _, idx, z_pre = self._encode_native(mels, want_c=False)
+            zq, _, idx, z_pre = self._encode_native(mels, want_c=False, want_pre=True)
             B, Tz, D = zq.shape
             z_st = torch.empty_like(zq)
             stats = torch.empty(2, device=zq.device)

@@ -92,16 +92,20 @@ class Vocoder(nn.Module):
 
     # ------------------------------------------------------------------ native handle
     def _native(self):
-        sd = self.state_dict()
-        ws = list(sd.values())
+        slots = self.__dict__.get("_slots")
+        if slots is None:                       # resolved once: state_dict() costs more than a short decode call's launch
+            slots = self.__dict__["_slots"] = _lib.WeightSlots(self, list(self.state_dict().keys()))
+        ws = slots.tensors()
+        key = _lib.WeightSlots.key(ws)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
         for w in ws:
             _lib.require_cuda(w, "Vocoder parameter")
             if w.dtype != torch.float32:
                 raise RuntimeError("Vocoder: parameters must be float32")
-        key = tuple((w.data_ptr(), w._version) for w in ws) + (ws[0].device.index,)
-        if self._handle is not None and key == self._handle_key:
-            return self._handle
+            _lib.require_same_device(w, ws[0], "a parameter")
         self._release()
+        sd = dict(zip(slots.names, ws))
         keep = []
 
         def p(name):
@@ -147,6 +151,7 @@ class Vocoder(nn.Module):
     def __getstate__(self):                             # the native handle is per object: a copy builds its own
         d = self.__dict__.copy()
         d["_handle"], d["_handle_key"] = None, None
+        d.pop("_slots", None)
         return d
 
     def refresh(self):
@@ -182,9 +187,9 @@ class Vocoder(nn.Module):
             raise RuntimeError("z and speaker must be integer tensors (nn.Embedding indices, network_vocoder.py:73,75)")
         z = z.detach().to(torch.int64).contiguous()
         speaker = speaker.detach().to(device=z.device, dtype=torch.int64).contiguous()
-        # nn.Embedding raises on an out-of-range index (network_vocoder.py:73,75); so do we (one tiny sync)
-        lo = torch.stack((z.min(), speaker.min())).min().item()
-        if lo < 0 or z.max().item() >= self.conf.size_i_codebook or speaker.max().item() >= self.conf.n_speakers:
+        # nn.Embedding raises on an out-of-range index (network_vocoder.py:73,75); so do we (ONE small read-back)
+        zlo, zhi, slo, shi = torch.stack((z.min(), z.max(), speaker.min(), speaker.max())).tolist()
+        if min(zlo, slo) < 0 or zhi >= self.conf.size_i_codebook or shi >= self.conf.n_speakers:
             raise IndexError("index out of range in self")
         return z, speaker
 
@@ -216,7 +221,7 @@ class Vocoder(nn.Module):
         nc = None
         if n_codes is not None:
             nc = (C.c_int * B)(*[int(v) for v in n_codes])
-        with torch.cuda.device(z.device):
+        with _lib.device_guard(z.device):
             _lib.check(_lib.load().vqcpc_vocoder_generate(
                 h, z.data_ptr(), speaker.data_ptr(), B, Tc, nc, seed, int(utt_base) & 0xFFFFFFFF, ids, wav.data_ptr(),
                 mulaw.data_ptr() if return_mulaw else None, int(max_steps), _lib.current_stream()))
