@@ -535,17 +535,22 @@ struct FusedP {
 
 // One GEMM stage for this wave: tile (LDS, 16 rows x K) x NT column tiles starting at ct0.  tot = fold over K blocks of
 // kcq q-steps (16 k each) of zero-started chains: first block (bias ? bias + chain : chain), later blocks tot + chain.
+// The first three q-steps' fragments of a stage, requested ahead of time (under the previous stage's epilogue and
+// LayerNorm, when the MFMA pipe would otherwise wait for the first bytes of the next weight matrix).
 template <int NT>
-__device__ __forceinline__ void rows16_gemm(const float *tile, const float4 *__restrict__ Wf, int ct0, int nq, int kcq,
-                                            const float *__restrict__ bias, f32x4 (&tot)[NT], int lane) {
-    const float4 *wp[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wp[j] = Wf + ((size_t)(ct0 + j) * nq) * 64 + lane;
-    float4 fr[4][NT];
+__device__ __forceinline__ void rows16_prefetch(const float4 *__restrict__ Wf, int ct0, int nq, float4 (&fr)[4][NT], int lane) {
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fr[u][j] = wp[j][(size_t)(u < nq ? u : nq - 1) * 64];
+        for (int j = 0; j < NT; ++j) fr[u][j] = Wf[(((size_t)(ct0 + j) * nq) + (u < nq ? u : nq - 1)) * 64 + lane];
+}
+
+template <int NT>
+__device__ __forceinline__ void rows16_gemm(const float *tile, const float4 *__restrict__ Wf, int ct0, int nq, int kcq,
+                                            const float *__restrict__ bias, f32x4 (&tot)[NT], int lane, float4 (&fr)[4][NT]) {
+    const float4 *wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = Wf + ((size_t)(ct0 + j) * nq) * 64 + lane;
     const float *arow = tile + (lane & 15) * FE_LD + (lane >> 4);
     float an[4] = {arow[0], arow[4], arow[8], arow[12]};
     f32x4 acc[NT];
@@ -690,7 +695,10 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
     __syncthreads();
 
     f32x4 tot[8];
-    rows16_gemm<8>(tile, p.conv_f, 8 * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane);
+    float4 fr[4][8];
+    rows16_prefetch<8>(p.conv_f, 8 * wave, K0 / 16, fr, lane);
+    rows16_gemm<8>(tile, p.conv_f, 8 * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane, fr);
+    if (p.stage != 0) rows16_prefetch<8>(p.fc_f[0], 8 * wave, 32, fr, lane);          // under the store + LayerNorm below
     __syncthreads();                                     // every wave has read its A operands
     rows16_store<8>(tile, tot, 8 * wave, lane);
     __syncthreads();
@@ -701,7 +709,8 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
     __syncthreads();
     if (rows16_dump(p, tile, 1, r0, tid)) return;
     for (int l = 0; l < 4; ++l) {
-        rows16_gemm<8>(tile, p.fc_f[l], 8 * wave, 32, 16, nullptr, tot, lane);
+        rows16_gemm<8>(tile, p.fc_f[l], 8 * wave, 32, 16, nullptr, tot, lane, fr);
+        if (l < 3) rows16_prefetch<8>(p.fc_f[l + 1], 8 * wave, 32, fr, lane);
         __syncthreads();
         rows16_store<8>(tile, tot, 8 * wave, lane);
         __syncthreads();
@@ -717,7 +726,9 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
     vq_load_tile(p.Ef, t0, lane, f0);
     vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
     f32x4 zt[1];
-    rows16_gemm<1>(tile, p.out_f, wave, 32, 16, p.out_b, zt, lane);
+    float4 fr1[4][1];
+    rows16_prefetch<1>(p.out_f, wave, 32, fr1, lane);
+    rows16_gemm<1>(tile, p.out_f, wave, 32, 16, p.out_b, zt, lane, fr1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
@@ -743,38 +754,36 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
 // Six launches instead of fourteen, same chains, same bits.  The K blocks of a chain fold are independent
 // zero-started chains, so a wave runs them interleaved (NBLK accumulators) instead of one dependent MFMA sequence.
 // ------------------------------------------------------------------------------------------
-template <int NBLK>
-__device__ __forceinline__ f32x4 rows16_gemm_blocks(const float *tile, const float4 *__restrict__ Wf, int ct, int kcq,
-                                                    const float *__restrict__ bias, int lane) {
-    const int nq = NBLK * kcq;
-    const float4 *wp = Wf + ((size_t)ct * nq) * 64 + lane;
+// A wave's whole weight slice (one 16-column tile, NQ q-steps) is requested up front -- 4 NQ registers -- so that the
+// loads fly under the A-tile load and the LayerNorm, and the MFMAs then run back to back (a 1-deep prefetch left every
+// step waiting ~0.3 us on L2: 10.4 us per launch, rocprofv3).
+template <int NQ>
+__device__ __forceinline__ void rows16_load_w(const float4 *__restrict__ Wf, int ct, int lane, float4 (&wf)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wf[q] = Wf[((size_t)ct * NQ + q) * 64 + lane];
+}
+template <int NBLK, int KCQ>
+__device__ __forceinline__ f32x4 rows16_gemm_pre(const float *tile, const float4 (&wf)[NBLK * KCQ], int ct,
+                                                 const float *__restrict__ bias, int lane) {
     const float *arow = tile + (lane & 15) * FE_LD + (lane >> 4);
     f32x4 acc[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 fr[2][NBLK];
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) fr[0][b] = wp[(size_t)(b * kcq) * 64];
-    for (int s = 0; s < kcq; s += 2) {                                 // kcq is even (4, 16 or 20)
+    for (int s = 0; s < KCQ; ++s) {
+        float a[NBLK][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int sn = s + u + 1 < kcq ? s + u + 1 : s + u;
+        for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) fr[u ^ 1][b] = wp[(size_t)(b * kcq + sn) * 64];
-            float a[NBLK][4];
+            for (int c = 0; c < 4; ++c) a[b][c] = arow[16 * (b * KCQ + s) + 4 * c];
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b)
+        for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][0], wf[b * KCQ + s].x, acc[b], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a[b][c] = arow[16 * (b * kcq + s + u) + 4 * c];
+        for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][1], wf[b * KCQ + s].y, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][0], fr[u][b].x, acc[b], 0, 0, 0);
+        for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][2], wf[b * KCQ + s].z, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][1], fr[u][b].y, acc[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][2], fr[u][b].z, acc[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][3], fr[u][b].w, acc[b], 0, 0, 0);
-        }
+        for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][3], wf[b * KCQ + s].w, acc[b], 0, 0, 0);
     }
     const float bv = bias ? bias[16 * ct + (lane & 15)] : 0.f;
     f32x4 tot;
@@ -794,7 +803,31 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = blockIdx.x, r0 = blockIdx.y * 16;
     if (layer == 0) {
         const int K0 = 4 * p.C;
-        for (int e = tid; e < 16 * K0; e += 256) {
+        const int ct = 4 * cg + wave, nq = K0 / 16;
+        // vmcnt retires in order: the gather's loads go FIRST, the weight slice behind them, so that waiting for the
+        // gather leaves the weights in flight
+        float gv[20];
+#pragma unroll
+        for (int n = 0; n < 20; ++n) {
+            const int e = tid + 256 * n, i = e & 15, kidx = e >> 4, m = r0 + i;
+            int c, tap;
+            if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
+            else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
+            float v = 0.f;
+            if (e < 16 * K0 && m < p.N) {
+                const int b = m / p.To, tt = m - b * p.To, ti = 2 * tt + tap - 1;
+                if (ti >= 0 && ti < p.T) v = p.mel[((size_t)b * p.C + c) * p.T + ti];
+            }
+            gv[n] = v;
+        }
+        float4 wc[20];
+        if (nq == 20) rows16_load_w<20>(p.conv_f, ct, lane, wc);          // C = 80 (the reference): whole slice up front
+#pragma unroll
+        for (int n = 0; n < 20; ++n) {
+            const int e = tid + 256 * n;
+            if (e < 16 * K0) tile[(e & 15) * FE_LD + (e >> 4)] = gv[n];
+        }
+        for (int e = tid + 256 * 20; e < 16 * K0; e += 256) {             // more than 80 channels: the rest, plainly
             const int i = e & 15, kidx = e >> 4, m = r0 + i;
             int c, tap;
             if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
@@ -807,13 +840,14 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
             tile[i * FE_LD + kidx] = v;
         }
         __syncthreads();
-        const int ct = 4 * cg + wave, nq = K0 / 16;
         f32x4 tot;
-        if (p.conv_mode == 1) tot = rows16_gemm_blocks<1>(tile, p.conv_f, ct, nq, nullptr, lane);
-        else if (nq == 20) tot = rows16_gemm_blocks<5>(tile, p.conv_f, ct, 4, nullptr, lane);
+        if (nq == 20 && p.conv_mode == 1) tot = rows16_gemm_pre<1, 20>(tile, wc, ct, nullptr, lane);
+        else if (nq == 20) tot = rows16_gemm_pre<5, 4>(tile, wc, ct, nullptr, lane);
         else {                                                            // other channel counts: the generic fold
             f32x4 t1[1];
-            rows16_gemm<1>(tile, p.conv_f, ct, nq, 4, nullptr, t1, lane);
+            float4 fr1[4][1];
+            rows16_prefetch<1>(p.conv_f, ct, nq, fr1, lane);
+            rows16_gemm<1>(tile, p.conv_f, ct, nq, p.conv_mode == 1 ? nq : 4, nullptr, t1, lane, fr1);
             tot = t1[0];
         }
 #pragma unroll
@@ -823,21 +857,30 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
         }
         return;
     }
-    // raw rows of the previous Linear / conv -> LDS, LayerNorm + ReLU in place
-    for (int e = tid; e < 16 * 128; e += 256) {
-        const int row = e >> 7, c4 = e & 127;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < p.N) v = ((const float4 *)in)[(size_t)(r0 + row) * 128 + c4];
+    // this wave's weight slice first (it does not depend on anything), then the raw rows of the previous Linear / conv
+    // -> LDS, LayerNorm + ReLU in place
+    // (vmcnt retires in order: the rows' loads go first, the weight slice behind them)
+    float4 av[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
+        av[n] = r0 + row < p.N ? ((const float4 *)in)[(size_t)(r0 + row) * 128 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 wf[32];
+    rows16_load_w<32>(layer < 5 ? p.fc_f[layer - 1] : p.out_f, layer < 5 ? 4 * cg + wave : wave, lane, wf);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
         float *d = tile + row * FE_LD + 4 * c4;
-        *(float2 *)d = make_float2(v.x, v.y);
-        *(float2 *)(d + 2) = make_float2(v.z, v.w);
+        *(float2 *)d = make_float2(av[n].x, av[n].y);
+        *(float2 *)(d + 2) = make_float2(av[n].z, av[n].w);
     }
     __syncthreads();
     rows16_layernorm(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
     __syncthreads();
     if (layer < 5) {
         const int ct = 4 * cg + wave;
-        const f32x4 tot = rows16_gemm_blocks<2>(tile, p.fc_f[layer - 1], ct, 16, nullptr, lane);
+        const f32x4 tot = rows16_gemm_pre<2, 16>(tile, wf, ct, nullptr, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = r0 + 4 * (lane >> 4) + r;
@@ -849,7 +892,7 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
     float4 f0[4], f1[4];
     vq_load_tile(p.Ef, t0, lane, f0);
     vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
-    const f32x4 zt = rows16_gemm_blocks<2>(tile, p.out_f, wave, 16, p.out_b, lane);
+    const f32x4 zt = rows16_gemm_pre<2, 16>(tile, wf, wave, p.out_b, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
