@@ -606,60 +606,73 @@ __device__ __forceinline__ void rows16_store(float *tile, const f32x4 (&tot)[NT]
         for (int r = 0; r < 4; ++r) tile[(4 * (lane >> 4) + r) * FE_LD + 16 * (ct0 + j) + (lane & 15)] = tot[j][r];
 }
 
-// LayerNorm(512) + ReLU of the tile in place: the half-wave-per-row procedure of ln512_kernel (ATen's order), two rounds
-// of 8 rows; the half-wave that computed a row's moments also normalises it.
+// LayerNorm(512) + ReLU of the tile in place: the half-wave-per-row procedure of ln512_kernel (ATen's order).  A half-wave
+// owns rows r and r + 8 and runs their two (serial, latency-bound) moment cascades interleaved; it then normalises both.
 __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__restrict__ g, const float *__restrict__ b,
                                                  float eps, const LnConst &k, int tid) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, ll = lane & 31;
     const int chunk = ll >> 3, l = ll & 7;
+    float *x[2] = {tile + (wave * 2 + half) * FE_LD, tile + (8 + wave * 2 + half) * FE_LD};
+    float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        float *x = tile + (round * 8 + wave * 2 + half) * FE_LD;
-        float m1 = 0.f, m2 = 0.f;
+    for (int j = 0; j < 16; ++j) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float xv = x[(chunk * 16 + j) * 8 + l];
-            const float d = xv - m1;
-            m1 = __builtin_fmaf(d, k.inv[j], m1);
-            m2 = __builtin_fmaf(d, xv - m1, m2);
+        for (int r = 0; r < 2; ++r) {
+            const float xv = x[r][(chunk * 16 + j) * 8 + l];
+            const float d = xv - m1[r];
+            m1[r] = __builtin_fmaf(d, k.inv[j], m1[r]);
+            m2[r] = __builtin_fmaf(d, xv - m1[r], m2[r]);
         }
-        float a1 = __shfl_down(m1, 8), a2 = __shfl_down(m2, 8);
-        {
-            const float delta = a1 - m1;
-            const float n1 = __builtin_fmaf(0.5f, delta, m1);
-            m2 = __builtin_fmaf((0.5f * 16.0f) * delta, delta, m2 + a2);
-            m1 = n1;
-        }
-        a1 = __shfl_down(m1, 16); a2 = __shfl_down(m2, 16);
-        {
-            const float delta = a1 - m1;
-            const float n1 = __builtin_fmaf(0.5f, delta, m1);
-            m2 = __builtin_fmaf((0.5f * 32.0f) * delta, delta, m2 + a2);
-            m1 = n1;
-        }
-        float M1 = 0.f, M2 = 0.f;
+    }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float s1 = __shfl(m1, half * 32 + q), s2 = __shfl(m2, half * 32 + q);
-            const float delta = s1 - M1;
-            M1 = __builtin_fmaf(k.sc[q], delta, M1);
-            M2 = M2 + __builtin_fmaf((delta * delta) * k.sc[q], (float)(64 * q), s2);
-        }
-        const float mean = M1, var = M2 / 512.0f;
-        const float sd = (float)sqrt((double)(var + eps));
-        const float rstd = (float)(1.0 / (double)sd);
+    for (int r = 0; r < 2; ++r) {                                       // chunk 1 -> 0, 3 -> 2 (16 + 16 vectors)
+        const float a1 = __shfl_down(m1[r], 8), a2 = __shfl_down(m2[r], 8);
+        const float delta = a1 - m1[r];
+        const float n1 = __builtin_fmaf(0.5f, delta, m1[r]);
+        m2[r] = __builtin_fmaf((0.5f * 16.0f) * delta, delta, m2[r] + a2);
+        m1[r] = n1;
+    }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = q * 64 + ll * 2;                              // 8-byte LDS accesses (the row stride is 8 mod 16)
-            const float2 xv = *(const float2 *)(x + e);
-            const float2 gv = *(const float2 *)(g + e);
-            const float2 bb = *(const float2 *)(b + e);
+    for (int r = 0; r < 2; ++r) {                                       // (chunks 2, 3) -> (chunks 0, 1) (32 + 32 vectors)
+        const float a1 = __shfl_down(m1[r], 16), a2 = __shfl_down(m2[r], 16);
+        const float delta = a1 - m1[r];
+        const float n1 = __builtin_fmaf(0.5f, delta, m1[r]);
+        m2[r] = __builtin_fmaf((0.5f * 32.0f) * delta, delta, m2[r] + a2);
+        m1[r] = n1;
+    }
+    float M1[2] = {0.f, 0.f}, M2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                                       // the 8 vector lanes, serially
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float s1 = __shfl(m1[r], half * 32 + q), s2 = __shfl(m2[r], half * 32 + q);
+            const float delta = s1 - M1[r];
+            M1[r] = __builtin_fmaf(k.sc[q], delta, M1[r]);
+            M2[r] = M2[r] + __builtin_fmaf((delta * delta) * k.sc[q], (float)(64 * q), s2);
+        }
+    }
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        mean[r] = M1[r];
+        const float var = M2[r] / 512.0f;
+        const float sd = (float)sqrt((double)(var + eps));              // both correctly rounded in fp32 (via fp64)
+        rstd[r] = (float)(1.0 / (double)sd);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = q * 64 + ll * 2;                                  // 8-byte LDS accesses (the row stride is 8 mod 16)
+        const float2 gv = *(const float2 *)(g + e);
+        const float2 bb = *(const float2 *)(b + e);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float2 xv = *(const float2 *)(x[r] + e);
             float2 o;
-            o.x = __builtin_fmaf((xv.x - mean) * rstd, gv.x, bb.x);
-            o.y = __builtin_fmaf((xv.y - mean) * rstd, gv.y, bb.y);
+            o.x = __builtin_fmaf((xv.x - mean[r]) * rstd[r], gv.x, bb.x);
+            o.y = __builtin_fmaf((xv.y - mean[r]) * rstd[r], gv.y, bb.y);
             o.x = o.x < 0.f ? 0.f : o.x;
             o.y = o.y < 0.f ? 0.f : o.y;
-            *(float2 *)(x + e) = o;
+            *(float2 *)(x[r] + e) = o;
         }
     }
 }
@@ -746,10 +759,11 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
 // ------------------------------------------------------------------------------------------
 // Small calls (a single utterance: BASELINE configs[0], encode.py:44-46): too few 16-row tiles to fill the chip with
 // whole-row workgroups, and each of those would still stream all 5 MB of weights.  Here the columns are split over
-// 8 workgroups per row tile (4 waves x one 16-column tile) and one launch covers one Linear:
-//   launch 0: im2col + conv                                -> raw rows
-//   launch l = 1..4: LayerNorm_{l-1} + ReLU of the raw rows ON LOAD (each of the 8 column workgroups repeats it for
-//                    its 16 rows: 16 x 512 elements, nothing next to the launch boundary it saves) + Linear_l -> raw rows
+// several workgroups per row tile and one launch covers one Linear:
+//   launch 0: im2col + conv (8 column groups: 4 waves x one 16-column tile)                     -> raw rows
+//   launch l = 1..4: LayerNorm_{l-1} + ReLU of the raw rows ON LOAD (every column workgroup repeats it for its 16 rows:
+//                    16 x 512 elements, nothing next to the launch boundary it saves) + Linear_l, 16 column groups of
+//                    2 column tiles x the 2 K halves of the chain fold                          -> raw rows
 //   launch 5: LayerNorm_4 + ReLU on load + encoder.14 + VQ search (one workgroup per row tile, as the fused tail)
 // Six launches instead of fourteen, same chains, same bits.  The K blocks of a chain fold are independent
 // zero-started chains, so a wave runs them interleaved (NBLK accumulators) instead of one dependent MFMA sequence.
@@ -866,8 +880,41 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
         const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
         av[n] = r0 + row < p.N ? ((const float4 *)in)[(size_t)(r0 + row) * 128 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (layer < 5) {
+        // Linear l: 16 column groups per row tile; a workgroup = 2 column tiles x the 2 K halves of the chain fold (they are
+        // independent zero-started chains: tot = c0 + c1), so a wave streams 16 KB of weights and issues 64 MFMAs
+        __shared__ float part[2][16][17];
+        const int ct = 2 * cg + (wave & 1), kh = wave >> 1;
+        float4 wh[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wh[q] = p.fc_f[layer - 1][((size_t)ct * 32 + 16 * kh + q) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
+            float *d = tile + row * FE_LD + 4 * c4;
+            *(float2 *)d = make_float2(av[n].x, av[n].y);
+            *(float2 *)(d + 2) = make_float2(av[n].z, av[n].w);
+        }
+        __syncthreads();
+        rows16_layernorm(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
+        __syncthreads();
+        const f32x4 acc = rows16_gemm_pre<1, 16>(tile + 256 * kh, wh, ct, nullptr, lane);      // k in [256 kh, 256 kh + 256)
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave & 1][4 * (lane >> 4) + r][lane & 15] = acc[r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = r0 + 4 * (lane >> 4) + r;
+                if (m < p.N) out[(size_t)m * 512 + 16 * ct + (lane & 15)] = acc[r] + part[wave & 1][4 * (lane >> 4) + r][lane & 15];
+            }
+        }
+        return;
+    }
     float4 wf[32];
-    rows16_load_w<32>(layer < 5 ? p.fc_f[layer - 1] : p.out_f, layer < 5 ? 4 * cg + wave : wave, lane, wf);
+    rows16_load_w<32>(p.out_f, wave, lane, wf);
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
@@ -878,16 +925,6 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
     __syncthreads();
     rows16_layernorm(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
     __syncthreads();
-    if (layer < 5) {
-        const int ct = 4 * cg + wave;
-        const f32x4 tot = rows16_gemm_pre<2, 16>(tile, wf, ct, nullptr, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = r0 + 4 * (lane >> 4) + r;
-            if (m < p.N) out[(size_t)m * 512 + 16 * ct + (lane & 15)] = tot[r];
-        }
-        return;
-    }
     const int tpw = p.n_emb / 64, t0 = wave * tpw;
     float4 f0[4], f1[4];
     vq_load_tile(p.Ef, t0, lane, f0);
@@ -1133,7 +1170,7 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
         float *a = e->bufA.as<float>(), *b = e->bufB.as<float>();
         hipLaunchKernelGGL(enc_split_kernel, dim3(8, ntiles), dim3(256), 0, s, p, 0, (const float *)nullptr, a);
         for (int l = 1; l <= 4; ++l) {
-            hipLaunchKernelGGL(enc_split_kernel, dim3(8, ntiles), dim3(256), 0, s, p, l, (const float *)a, b);
+            hipLaunchKernelGGL(enc_split_kernel, dim3(16, ntiles), dim3(256), 0, s, p, l, (const float *)a, b);
             float *t = a; a = b; b = t;
         }
         hipLaunchKernelGGL(enc_split_kernel, dim3(1, ntiles), dim3(256), 0, s, p, 5, (const float *)a, (float *)nullptr);

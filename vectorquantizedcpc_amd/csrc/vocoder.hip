@@ -810,6 +810,19 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
 // ------------------------------------------------------------------------------------------
 #define PS_NB 64
 typedef unsigned long long u64;
+// Timeline stamps of workgroup PS_STAMP_BLK (100 MHz wall clock), steps 256..383, for tools/persist_timeline.py: compiled
+// in only with -DVQCPC_PS_STAMPS (a debug build under build/stamps/, never the shipped library).
+#ifdef VQCPC_PS_STAMPS
+#define PS_STAMP_BLK 5
+__device__ unsigned long long g_ps_stamps[128 * 12];
+#define PS_STAMP(i) do { if (blk == PS_STAMP_BLK && (lane & 63) == 0 && t >= 256 && t < 384) \
+        g_ps_stamps[(t - 256) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int vqcpc_debug_ps_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define PS_STAMP(i) do { } while (0)
+#endif
 
 struct PersistP {
     const float *w_hh, *w_fc1, *b_fc1, *w_fc2, *b_fc2;
@@ -944,6 +957,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
         volatile int *ab = &s_abort[t & 1];
         if (wave == 7) {
             // ---- x_{t-1} from the 64 candidates of step t-1, then the cell update of the owned units
+            PS_STAMP(0);
             int x = NC / 2;
             if (t > 0 && !dead) {
                 unsigned v[1];
@@ -979,6 +993,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     if (p.mulaw) p.mulaw[t - 1] = x;
                 }
             }
+            PS_STAMP(1);                                                 // x known
             if (!dead) {
                 if (t % p.upsample == 0 && lane < UPB) {                 // next conditioning frame (once per hop)
                     const int f = t / p.upsample < p.F ? t / p.upsample : p.F - 1;
@@ -995,6 +1010,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     hold = (1.0f - z) * nn + z * hold;
                     ps_store(p.gh + my_unit, ((u64)tag << 32) | __float_as_uint(hold));
                 }
+                PS_STAMP(2);                                             // own h published
                 // ---- gather h_t
                 unsigned hv[SW];
                 if (ps_sweep<SW>(p.gh, lane, tag, hv, p.abort_flag)) {
@@ -1003,7 +1019,9 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 } else dead = true;
             }
             if (dead) *ab = 1;
+            PS_STAMP(3);                                                 // h_t gathered
             ps_barrier();                                                // A: h_t in LDS
+            PS_STAMP(4);
             if (!dead) {
                 unsigned av[Hf / 64];
                 if (ps_sweep<Hf / 64>(p.ga, lane, tag, av, p.abort_flag)) {
@@ -1011,7 +1029,9 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     for (int j = 0; j < Hf / 64; ++j) a1buf[ps_perm(lane + 64 * j)] = __uint_as_float(av[j]);
                 } else { dead = true; *ab = 1; }
             }
+            PS_STAMP(5);                                                 // a_t gathered
             ps_barrier();                                                // B: a_t and W_hh h_t in LDS
+            PS_STAMP(6);
         } else if (wave == 0) {
             float gum = 0.f;
             if (lane >= 32 && (lane & 7) == 0) {                         // the draw's noise does not depend on the data
@@ -1026,6 +1046,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 v += fc_bias;
                 if ((lane & 7) == 0) ps_store(p.ga + RPB * blk + row_local, ((u64)tag << 32) | __float_as_uint(v > 0.f ? v : 0.f));
             }
+            PS_STAMP(7);                                                 // fc1 rows published
             ps_barrier();                                                // B
             if (*ab == 0 && lane >= 32) {
                 float w2[32];
@@ -1044,6 +1065,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 }
                 if (lane == 32) ps_store(p.gc + blk, ((u64)((tag << 8) | (unsigned)cls) << 32) | __float_as_uint(sc));
             }
+            PS_STAMP(8);                                                 // candidate published
         } else {
             ps_barrier();                                                // A
             if (*ab == 0) {
@@ -1051,6 +1073,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 const float v = ps_combine(acc, lane);
                 if (gru_lane && (lane & 7) == 0) gsum[row_local] = v;
             }
+            if (wave == 1) PS_STAMP(9);                                  // W_hh h_t chains done
             ps_barrier();                                                // B
         }
         if (*ab != 0) { aborted = true; break; }                         // read after barrier B: uniform for the workgroup
