@@ -829,7 +829,7 @@ struct PersistP {
     const float4 *Gemb4, *bh4;
     const float *Gcond;               // [F][3Hr] conditioning rows of this utterance (W_ih[:, de:] cond + b_ih)
     const float *mulaw_tab;
-    u64 *gh, *ga, *gc;                // granules: [Hr] h_t, [Hf] a_t, [PS_NB] candidates
+    u64 *gh, *ga, *gc;                // granules of h_t, a_t, the candidates: [PS_NB][PS_PAD] each (a line per workgroup)
     unsigned *abort_flag;             // pinned HOST memory (system-scope accesses): the host reads it without a HIP call
     float *wav; int64_t *mulaw;
     int n_steps, upsample, F;
@@ -880,15 +880,42 @@ __device__ __forceinline__ float ps_combine(float acc, int lane) {
     return ((q + q1) + q2) + q3;
 }
 
+// First argmax over the 64 lanes of (score, class), classes ascending with the lane: max of an order-preserving integer
+// image of the score by four DPP steps inside each row of 16 lanes and four readlanes across rows, then the first lane
+// that holds it (six __shfl_xor pairs -- ds_bpermute round trips -- took ~0.5 us of every sample step).
+__device__ __forceinline__ int ps_argmax64(float score, int cls) {
+    unsigned u = __float_as_uint(score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    unsigned m = u;
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));    // row_mirror
+    const unsigned m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 16),
+                   m2 = __builtin_amdgcn_readlane(m, 32), m3 = __builtin_amdgcn_readlane(m, 48);
+    const unsigned best = max(max(m0, m1), max(m2, m3));
+    const unsigned long long hit = __ballot(u == best);
+    const int first = __ffsll((long long)hit) - 1;
+    return __builtin_amdgcn_readlane(cls, first);
+}
+
+// Every workgroup's granules start on a 128-byte line of their own (16 granules): lines shared by writers on different
+// CUs serialised the write-through stores -- the 64 one-granule candidate stores into 4 lines took 2.7 us to be seen.
+#define PS_PAD 16
+__device__ __forceinline__ int ps_slot(int idx, int per_blk) { return (idx / per_blk) * PS_PAD + idx % per_blk; }
+
 // Sweep N granules per lane (stride 64) until every tag equals `tag`; bounded.  Returns false on timeout / abort.
 template <int N>
-__device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, unsigned tag, unsigned (&val)[N], unsigned *abort_flag) {
+__device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, int per_blk, unsigned tag, unsigned (&val)[N], unsigned *abort_flag) {
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    int slot[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) slot[j] = ps_slot(lane + 64 * j, per_blk);
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const u64 x = ps_load(g + lane + 64 * j);
+            const u64 x = ps_load(g + slot[j]);
             val[j] = (unsigned)x;
             ok &= (unsigned)(x >> 32) == tag;
         }
@@ -965,7 +992,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 {   // candidates carry (tag << 8 | class) in the high word and the score in the low word
                     const u64 t0 = __builtin_amdgcn_s_memrealtime();
                     for (unsigned spins = 0;; ++spins) {
-                        g = ps_load(p.gc + lane);
+                        g = ps_load(p.gc + lane * PS_PAD);
                         if (__all((unsigned)(g >> 40) == (unsigned)t)) break;
                         if ((spins & 63) == 63) {
                             const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;
@@ -979,15 +1006,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     }
                 }
                 (void)v;
-                float best = __uint_as_float((unsigned)g);
-                int cls = (int)((g >> 32) & 255u);
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {                 // first argmax: higher score, then lower class
-                    const float os = __shfl_xor(best, off);
-                    const int oc = __shfl_xor(cls, off);
-                    if (os > best || (os == best && oc < cls)) { best = os; cls = oc; }
-                }
-                x = cls;
+                x = ps_argmax64(__uint_as_float((unsigned)g), (int)((g >> 32) & 255u));    // higher score, then lower class
                 if (blk == 0 && lane == 0 && !dead) {                    // network_vocoder.py:78 output: sample t-1
                     if (p.wav) p.wav[t - 1] = p.mulaw_tab[x];
                     if (p.mulaw) p.mulaw[t - 1] = x;
@@ -1008,12 +1027,12 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     const float z = sigmoidf_((eq.y + gcq.y) + (gz + bq.y));
                     const float nn = tanhf((eq.z + gcq.z) + r * (gn + bq.z));
                     hold = (1.0f - z) * nn + z * hold;
-                    ps_store(p.gh + my_unit, ((u64)tag << 32) | __float_as_uint(hold));
+                    ps_store(p.gh + blk * PS_PAD + lane, ((u64)tag << 32) | __float_as_uint(hold));
                 }
                 PS_STAMP(2);                                             // own h published
                 // ---- gather h_t
                 unsigned hv[SW];
-                if (ps_sweep<SW>(p.gh, lane, tag, hv, p.abort_flag)) {
+                if (ps_sweep<SW>(p.gh, lane, UPB, tag, hv, p.abort_flag)) {
 #pragma unroll
                     for (int j = 0; j < SW; ++j) hbuf[ps_perm(lane + 64 * j)] = __uint_as_float(hv[j]);
                 } else dead = true;
@@ -1024,7 +1043,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
             PS_STAMP(4);
             if (!dead) {
                 unsigned av[Hf / 64];
-                if (ps_sweep<Hf / 64>(p.ga, lane, tag, av, p.abort_flag)) {
+                if (ps_sweep<Hf / 64>(p.ga, lane, RPB, tag, av, p.abort_flag)) {
 #pragma unroll
                     for (int j = 0; j < Hf / 64; ++j) a1buf[ps_perm(lane + 64 * j)] = __uint_as_float(av[j]);
                 } else { dead = true; *ab = 1; }
@@ -1044,7 +1063,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
                 float v = ps_combine(acc, lane);
                 v += fc_bias;
-                if ((lane & 7) == 0) ps_store(p.ga + RPB * blk + row_local, ((u64)tag << 32) | __float_as_uint(v > 0.f ? v : 0.f));
+                if ((lane & 7) == 0) ps_store(p.ga + blk * PS_PAD + row_local, ((u64)tag << 32) | __float_as_uint(v > 0.f ? v : 0.f));
             }
             PS_STAMP(7);                                                 // fc1 rows published
             ps_barrier();                                                // B
@@ -1063,7 +1082,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                     const int oc = __shfl_xor(cls, off);
                     if (os > sc || (os == sc && oc < cls)) { sc = os; cls = oc; }
                 }
-                if (lane == 32) ps_store(p.gc + blk, ((u64)((tag << 8) | (unsigned)cls) << 32) | __float_as_uint(sc));
+                if (lane == 32) ps_store(p.gc + blk * PS_PAD, ((u64)((tag << 8) | (unsigned)cls) << 32) | __float_as_uint(sc));
             }
             PS_STAMP(8);                                                 // candidate published
         } else {
@@ -1084,20 +1103,13 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
         bool ok = true;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 0;; ++spins) {
-            g = ps_load(p.gc + lane);
+            g = ps_load(p.gc + lane * PS_PAD);
             if (__all((unsigned)(g >> 40) == (unsigned)n)) break;
             if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
                                        __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        float best = __uint_as_float((unsigned)g);
-        int cls = (int)((g >> 32) & 255u);
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float os = __shfl_xor(best, off);
-            const int oc = __shfl_xor(cls, off);
-            if (os > best || (os == best && oc < cls)) { best = os; cls = oc; }
-        }
+        const int cls = ps_argmax64(__uint_as_float((unsigned)g), (int)((g >> 32) & 255u));
         if (ok && lane == 0) {
             if (p.wav) p.wav[n - 1] = p.mulaw_tab[cls];
             if (p.mulaw) p.mulaw[n - 1] = cls;
@@ -1653,7 +1665,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
     if (v->persistent != 0 && B == 1 && !inputs && Hr == 896 && d.Hf == 256 && d.n_cls == 256 && lens[Bp] > 0 &&
         lens[Bp] < (1 << 24)) {
-        const size_t ngr = (size_t)Hr + d.Hf + PS_NB;
+        const size_t ngr = (size_t)3 * PS_NB * PS_PAD;       // h_t, a_t, candidates: one 128-B line per workgroup each
         TRY(v->px.reserve(ngr * sizeof(u64)));
         HIP_TRY(hipMemsetAsync(v->px.p, 0, ngr * sizeof(u64), s));
         unsigned *abort_dev = nullptr;
@@ -1661,7 +1673,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         PersistP pp{};
         pp.w_hh = v->w_hh; pp.w_fc1 = v->w_fc1; pp.b_fc1 = v->b_fc1; pp.w_fc2 = v->w_fc2; pp.b_fc2 = v->b_fc2;
         pp.Gemb4 = v->Gemb4; pp.bh4 = v->bh4; pp.Gcond = v->gcond.as<float>(); pp.mulaw_tab = v->mulaw_tab;
-        pp.gh = v->px.as<u64>(); pp.ga = pp.gh + Hr; pp.gc = pp.ga + d.Hf;
+        pp.gh = v->px.as<u64>(); pp.ga = pp.gh + PS_NB * PS_PAD; pp.gc = pp.ga + PS_NB * PS_PAD;
         pp.abort_flag = abort_dev;
         pp.wav = wav; pp.mulaw = mulaw; pp.n_steps = lens[Bp]; pp.upsample = d.upsample_t; pp.F = T2;
         pp.utt = utt[0]; pp.seed = seed;
