@@ -848,6 +848,8 @@ __device__ __forceinline__ void ps_store(u64 *p, u64 v) { __hip_atomic_store(p, 
 __device__ __forceinline__ int ps_perm(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
 
 // one accumulator chain: NS super-steps of this K quarter, components c0 then c0 + 2 (the x/z or y/w MFMA operands)
+// (hipcc keeps one or two operand reads in flight here -- read, wait, 4 fmas.  Forcing a deeper window, by a register
+// window, by volatile reads or by sched_group_barrier, each made it spill 70-240 registers; measured alternatives dropped.)
 template <int NS>
 __device__ __forceinline__ float ps_chain(const float (&w)[8 * NS], const float4 *hb, int kw, int c0) {
     float acc = 0.f;
@@ -872,11 +874,15 @@ __device__ __forceinline__ void ps_load_weights(const float *Wrow, int kw, int c
 }
 // the 8 chains of a row sit in 8 consecutive lanes (index 2 kw + a): returns, in the row's first lane, the row sum in
 // the order of the launch-per-step kernels
+// (DPP moves inside the row of 16 lanes instead of ds_bpermute round trips; only the row's first lane is meaningful)
+#define PS_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
 __device__ __forceinline__ float ps_combine(float acc, int lane) {
-    const float other = __shfl_xor(acc, 1);
+    (void)lane;
+    const float other = PS_DPP(acc, 0xB1);             // quad_perm [1,0,3,2]: lane ^ 1
     const float q = acc + other;                       // a0 + a1 (both lanes hold it)
-    const int base = lane & ~7;
-    const float q1 = __shfl(q, base + 2), q2 = __shfl(q, base + 4), q3 = __shfl(q, base + 6);
+    const float q1 = PS_DPP(q, 0x4E);                  // quad_perm [2,3,0,1]: lane ^ 2 (= base + 2 in the first lane)
+    const float q2 = PS_DPP(q, 0x104);                 // row_shl:4: lane + 4
+    const float q3 = PS_DPP(q, 0x106);                 // row_shl:6: lane + 6
     return ((q + q1) + q2) + q3;
 }
 
@@ -984,6 +990,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
         volatile int *ab = &s_abort[t & 1];
         if (wave == 7) {
             // ---- x_{t-1} from the 64 candidates of step t-1, then the cell update of the owned units
+            __builtin_amdgcn_s_setprio(3);
             PS_STAMP(0);
             int x = NC / 2;
             if (t > 0 && !dead) {
@@ -1059,7 +1066,8 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 gum = -logf(-logf(((float)(wd >> 9) + 0.5f) * (1.0f / 8388608.0f)));
             }
             ps_barrier();                                                // A
-            if (*ab == 0 && lane < 32) {
+            __builtin_amdgcn_s_setprio(3);                               // fc1 / fc2 are on the critical path; the W_hh chains
+            if (*ab == 0 && lane < 32) {                                 // that share the SIMDs are not
                 const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
                 float v = ps_combine(acc, lane);
                 v += fc_bias;
@@ -1084,6 +1092,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
                 }
                 if (lane == 32) ps_store(p.gc + blk * PS_PAD, ((u64)((tag << 8) | (unsigned)cls) << 32) | __float_as_uint(sc));
             }
+            __builtin_amdgcn_s_setprio(0);
             PS_STAMP(8);                                                 // candidate published
         } else {
             ps_barrier();                                                // A
