@@ -228,6 +228,23 @@ int vqcpc_melfront_frames(const vqcpc_melfront *f, int n_samples);
 int vqcpc_melfront_run(vqcpc_melfront *f, const float *wav, const int *lens, int B, int Lmax, float *mel,
                        void *stream);
 
+/* ------------------------------------------------------------------ Resampling ---- */
+
+/* Replaces the resampling inside librosa.load(path, sr=cfg.preprocessing.sr) (convert.py:54-56): librosa ^0.8's
+ * res_type "kaiser_best" = resampy's band-limited sinc interpolation (64 zero crossings, 512 table entries per crossing,
+ * Kaiser taper, linear interpolation between entries), fp64 arithmetic, fp32 result.  resampy is absent offline: parity
+ * unpinned (oracle/resample_ref.py restates the algorithm and its published constants). */
+typedef struct vqcpc_resampler vqcpc_resampler;
+int vqcpc_resampler_create(int sr_in, int sr_out, vqcpc_resampler **out);
+void vqcpc_resampler_destroy(vqcpc_resampler *r);
+/* Output samples of an n_in-sample signal: ceil(n_in * sr_out / sr_in), as librosa.resample(fix=True). */
+int vqcpc_resampler_out_len(const vqcpc_resampler *r, int n_in);
+/* wav_in DEVICE (B, Lin_max) fp32, lens_in HOST (B) valid samples; wav_out DEVICE (B, Lout_max) fp32 with
+ * Lout_max >= vqcpc_resampler_out_len(max lens_in): row b holds its utterance's resampled samples, zeros behind them.
+ * Does not synchronise (the lengths travel as kernel arguments). */
+int vqcpc_resampler_run(vqcpc_resampler *r, const float *wav_in, const int *lens_in, int B, int Lin_max,
+                        float *wav_out, int Lout_max, void *stream);
+
 /* ------------------------------------------------------------------ Loudness ---- */
 
 /* Replaces pyloudnorm.Meter(sr) (convert.py:50) for mono audio: ITU-R BS.1770-4 gated integrated

@@ -20,6 +20,7 @@ SYMBOLS = [
     "vqcpc_melfront_create", "vqcpc_melfront_destroy", "vqcpc_melfront_frames", "vqcpc_melfront_run",
     "vqcpc_loudness_create", "vqcpc_loudness_destroy", "vqcpc_loudness_blocks", "vqcpc_loudness_integrated",
     "vqcpc_loudness_normalize",
+    "vqcpc_resampler_create", "vqcpc_resampler_destroy", "vqcpc_resampler_out_len", "vqcpc_resampler_run",
 ]
 
 
@@ -91,6 +92,11 @@ def load():
     lib.vqcpc_loudness_blocks.argtypes = [vp, i32]
     lib.vqcpc_loudness_integrated.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, vp, vp]
     lib.vqcpc_loudness_normalize.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, vp, vp]
+    lib.vqcpc_resampler_create.argtypes = [i32, i32, C.POINTER(vp)]
+    lib.vqcpc_resampler_destroy.argtypes = [vp]
+    lib.vqcpc_resampler_destroy.restype = None
+    lib.vqcpc_resampler_out_len.argtypes = [vp, i32]
+    lib.vqcpc_resampler_run.argtypes = [vp, vp, C.POINTER(C.c_int), i32, i32, vp, i32, vp]
     _lib = lib
     return lib
 

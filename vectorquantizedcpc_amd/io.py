@@ -29,17 +29,20 @@ def load_mel(path) -> torch.Tensor:
 
 
 def load_wav(path, sr: int = 16000) -> torch.Tensor:
-    """16 kHz mono waveform as float32 in [-1, 1] (``convert.py:54-56`` loads with librosa at cfg sr;
-    resampling is not done here: a file at another rate is an error)."""
+    """Mono waveform at ``sr`` as float32 in [-1, 1]: ``librosa.load(path, sr=sr)`` (``convert.py:54-56``).  A file stored
+    at another rate is resampled like librosa does (``preprocess.resample``: kaiser_best sinc interpolation, on the HIP
+    device -- so that case needs a GPU; the result comes back as a CPU tensor like the other case)."""
     from scipy.io import wavfile
     rate, a = wavfile.read(str(Path(path).with_suffix(".wav")))
-    if rate != sr:
-        raise ValueError(f"{path}: sample rate {rate}, expected {sr} (resample offline)")
     if a.ndim > 1:
-        a = a.mean(axis=1)
+        a = a.mean(axis=1)                    # librosa.load(mono=True)
     if a.dtype.kind == "i":
         a = a.astype(np.float32) / float(np.iinfo(a.dtype).max + 1)
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    w = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    if rate != sr:
+        from .preprocess import resample
+        w = resample(w.cuda(), rate, sr).cpu()
+    return w
 
 
 def save_frames_text(path, frames) -> None:

@@ -77,3 +77,38 @@ def mulaw_decode(y, mu: int):
     """``preprocess.py:30-35``: mu-law [-1, 1] -> linear [-1, 1]."""
     mu = mu - 1
     return np.sign(y) / mu * ((1 + mu) ** np.abs(y) - 1)
+
+
+_resamplers = {}
+
+
+@torch.no_grad()
+def resample(wave, sr_in: int, sr_out: int, lengths=None) -> torch.Tensor:
+    """The resampling ``librosa.load(path, sr=sr_out)`` applies to a file stored at ``sr_in`` (``convert.py:54-56``):
+    librosa ^0.8 ``res_type='kaiser_best'`` (resampy's band-limited sinc interpolation) on the HIP device.
+
+    ``wave`` (L,) -> (ceil(L * sr_out / sr_in),); (B, Lmax) with ``lengths`` -> (B, ceil(Lmax * ratio)), each row zero behind
+    its own resampled length.  resampy is not available offline: checked against ``oracle/resample_ref.py`` -- parity unpinned.
+    """
+    if isinstance(wave, np.ndarray):
+        wave = torch.from_numpy(np.ascontiguousarray(wave, dtype=np.float32)).cuda()
+    _lib.require_cuda(wave, "wave")
+    single = wave.dim() == 1
+    w = (wave[None] if single else wave).detach().to(torch.float32).contiguous()
+    if sr_in == sr_out:
+        return w[0].clone() if single else w.clone()
+    B, Lmax = w.shape
+    lens = [Lmax] * B if lengths is None else [int(v) for v in lengths]
+    key = (int(sr_in), int(sr_out), w.device.index)
+    lib = _lib.load()
+    if key not in _resamplers:
+        h = C.c_void_p()
+        with torch.cuda.device(w.device):
+            _lib.check(lib.vqcpc_resampler_create(int(sr_in), int(sr_out), C.byref(h)))
+        _resamplers[key] = h
+    h = _resamplers[key]
+    Lout = lib.vqcpc_resampler_out_len(h, Lmax)
+    out = torch.empty(B, Lout, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.vqcpc_resampler_run(h, w.data_ptr(), (C.c_int * B)(*lens), B, Lmax, out.data_ptr(), Lout, _lib.current_stream()))
+    return out[0] if single else out
