@@ -291,14 +291,24 @@ def run_manifest(enc, voc, dev, n_utt, max_batch):
 def gru_roofline(voc, n_utt, step_us):
     """`roofline` object for the GRU-step kernel of the LAST generate() call: HIP events around 2000
     back-to-back launches on the launch stream (vqcpc_vocoder_kernel_times)."""
-    gru_us, fc1_us, fc2_us, per_launch, kind = voc.kernel_times(2000)
+    step_tflops = FLOP_PER_SAMPLE * n_utt / (step_us * 1e-6) / 1e12
+    try:
+        gru_us, fc1_us, fc2_us, per_launch, kind = voc.kernel_times(2000)
+    except RuntimeError:
+        # a single utterance ran on the persistent decoder: ONE launch for the whole call, nothing per step to time
+        return {"bound": "mfma", "kernel": "ar_persist_kernel<14> (persistent single-utterance decoder: one launch per call, "
+                                           "weights in registers, in-kernel exchanges; latency-bound by three exchanges per sample)",
+                "achieved": step_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / FP32_PEAK_TFLOPS,
+                "traffic": None, "flop_per_launch": None, "avg_launch_us": None, "utterances_per_launch": n_utt,
+                "how": "HIP events around the one launch / samples",
+                "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
+                                "flop": FLOP_PER_SAMPLE * n_utt, "how": "HIP events around the launch / samples per utterance"}}
     per_launch = min(int(per_launch), n_utt)                 # utterances one launch covers (one tile group)
     names = {0: "ar_gru_kernel<14,1> (one tile)", 1: "ar_gru_kernel<14,2> (two tiles per workgroup)",
              2: "ar_gru_big_kernel<14> (LDS-staged state, full 16-row gate tiles)",
              3: "ar_gru16_kernel<14> (full 16-row gate tiles, small batch)"}
     flop = 2.0 * GRU_MAC * per_launch
     achieved = flop / (gru_us * 1e-6) / 1e12
-    step_tflops = FLOP_PER_SAMPLE * n_utt / (step_us * 1e-6) / 1e12
     # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
     alg_bytes = 4.0 * (GRU_MAC + per_launch * (2 * 896 + 2 * 3 * 896))
     return {"bound": "mfma", "kernel": names.get(int(kind), "ar_gru") + ": W_hh h for all utterances + GRU cell update",
@@ -325,7 +335,7 @@ def attach_traffic(roof):
     if pmc.get("kernel_source_sha") != kernel_source_sha():
         roof["traffic_source"] = f"stale: {os.path.relpath(TRAFFIC_JSON, ROOT)} was measured on other kernel sources; re-run tools/collect_traffic.py"
         return
-    if pmc.get("utterances") != roof["utterances_per_launch"]:
+    if roof.get("avg_launch_us") is None or pmc.get("utterances") != roof["utterances_per_launch"]:
         roof["traffic_source"] = "offline file covers another batch size"
         return
     roof["traffic"] = pmc["traffic_bytes_per_launch"]

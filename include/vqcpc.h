@@ -241,7 +241,8 @@ void vqcpc_resampler_destroy(vqcpc_resampler *r);
 int vqcpc_resampler_out_len(const vqcpc_resampler *r, int n_in);
 /* wav_in DEVICE (B, Lin_max) fp32, lens_in HOST (B) valid samples; wav_out DEVICE (B, Lout_max) fp32 with
  * Lout_max >= vqcpc_resampler_out_len(max lens_in): row b holds its utterance's resampled samples, zeros behind them.
- * Does not synchronise (the lengths travel as kernel arguments). */
+ * Does not synchronise (the lengths travel as kernel arguments), except when a call needs a longer output-clock table than
+ * any before it on this handle. */
 int vqcpc_resampler_run(vqcpc_resampler *r, const float *wav_in, const int *lens_in, int B, int Lin_max,
                         float *wav_out, int Lout_max, void *stream);
 

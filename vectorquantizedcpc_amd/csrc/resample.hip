@@ -17,6 +17,12 @@ struct vqcpc_resampler {
     double ratio, scale, time_increment;
     int num_table, index_step, nwin;
     double *win = nullptr, *delta = nullptr;     // device, nwin entries each
+    // resampy advances its output clock by repeated fp64 addition (time_register += time_increment); t * increment
+    // differs from that sum in the last bits, and where the clock lands within rounding of an integer the two pick
+    // different filter phases (resampy's integer index step makes that a 5e-4 jump).  So the clock values are produced
+    // by the same sequential additions on the host, once, and kept on the device (grow-only).
+    DevBuf treg;
+    int treg_len = 0;
 };
 
 #define RS_MAXB 256
@@ -25,7 +31,7 @@ struct RsLens { int n_in[RS_MAXB]; };
 __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__ x, float *__restrict__ y, RsLens lens,
                                                        int Lin_max, int Lout_max, const double *__restrict__ win,
                                                        const double *__restrict__ delta, int nwin, int num_table, int index_step,
-                                                       double ratio, double scale, double time_increment) {
+                                                       double ratio, double scale, const double *__restrict__ treg) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (t >= Lout_max) return;
     const int n_orig = lens.n_in[b];
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
     float out = 0.f;
     if (t < n_res) {
         const float *xb = x + (size_t)b * Lin_max;
-        const double time_register = (double)t * time_increment;
+        const double time_register = treg[t];
         const int n = (int)time_register;
         double acc = 0.0;
         double frac = scale * (time_register - (double)n);
@@ -76,6 +82,7 @@ extern "C" void vqcpc_resampler_destroy(vqcpc_resampler *r) {
     if (!r) return;
     if (r->win) (void)hipFree(r->win);
     if (r->delta) (void)hipFree(r->delta);
+    r->treg.release();
     delete r;
 }
 
@@ -135,13 +142,24 @@ extern "C" int vqcpc_resampler_run(vqcpc_resampler *r, const float *wav_in, cons
         VQ_REQUIRE(vqcpc_resampler_out_len(r, lens_in[b]) <= Lout_max, "vqcpc_resampler_run: output row too short for utterance %d", b);
     }
     hipStream_t s = (hipStream_t)stream;
+    if (Lout_max > r->treg_len) {                               // grow the clock table (rare: synchronises once)
+        int want = 1 << 16;
+        while (want < Lout_max) want <<= 1;
+        std::vector<double> tr((size_t)want);
+        double acc = 0.0;
+        for (int t = 0; t < want; ++t) { tr[t] = acc; acc += r->time_increment; }
+        HIP_TRY(hipStreamSynchronize(s));                       // earlier launches may still read the old table
+        TRY(r->treg.reserve((size_t)want * sizeof(double)));
+        HIP_TRY(hipMemcpy(r->treg.p, tr.data(), (size_t)want * sizeof(double), hipMemcpyHostToDevice));
+        r->treg_len = want;
+    }
     for (int b0 = 0; b0 < B; b0 += RS_MAXB) {                    // lengths travel as kernel arguments: no host-table upload, no sync
         const int nb = B - b0 < RS_MAXB ? B - b0 : RS_MAXB;
         RsLens lens{};
         for (int b = 0; b < nb; ++b) lens.n_in[b] = lens_in[b0 + b];
         hipLaunchKernelGGL(resample_kernel, dim3((Lout_max + 255) / 256, nb), dim3(256), 0, s, wav_in + (size_t)b0 * Lin_max,
                            wav_out + (size_t)b0 * Lout_max, lens, Lin_max, Lout_max, r->win, r->delta, r->nwin, r->num_table,
-                           r->index_step, r->ratio, r->scale, r->time_increment);
+                           r->index_step, r->ratio, r->scale, r->treg.as<double>());
     }
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
