@@ -201,7 +201,7 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
  * slots: continuous batching -- decode with this many slots, each running utterances back to back
  * (0 = one slot per utterance).  big_min_tiles: utterance tiles (of 16) from which the LDS-staged
- * large-batch GRU kernel is used (default 6, 0 = never).  two_groups: run calls of 3..big_min_tiles-1
+ * large-batch GRU kernel is used (default 5, 0 = never).  two_groups: run calls of 3..big_min_tiles-1
  * tiles, or of >= 2*big_min_tiles tiles, as two independent tile groups on two streams (default 1). */
 int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
 

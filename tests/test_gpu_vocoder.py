@@ -195,7 +195,7 @@ def test_tile_groups_and_large_batch_kernel_are_bit_identical():
             voc.set_option("slots", 0)
     finally:
         voc.set_option("two_groups", 1)
-        voc.set_option("big_min_tiles", 6)
+        voc.set_option("big_min_tiles", 5)
         voc.set_option("slots", 0)
     ref = outs["one_group"]
     assert int((ref != 0).sum()) > 10000

@@ -33,5 +33,5 @@ for B in sizes:
         ms, n = voc.last_timing()
         kt = voc.kernel_times(2000)
         print(f"{B},{name},{kt[0]:.3f},{kt[1]:.3f},{kt[2]:.3f},{int(kt[3])},{int(kt[4])},{ms * 1e3 / n:.3f}", flush=True)
-        voc.set_option("big_min_tiles", 6)
+        voc.set_option("big_min_tiles", 5)
         voc.set_option("two_groups", 1)

@@ -1298,7 +1298,8 @@ struct vqcpc_vocoder {
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
-    int big_min_tiles = 6;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never)
+    int big_min_tiles = 5;               // utterance tiles from which the LDS-staged GRU kernel is used (0 = never);
+                                         // measured (profiles/r02_gru_variants.csv): 17.2 vs 19.0 us per step at 5 tiles, 17.2 vs 14.9 at 4
     bool big_attr_set = false;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
