@@ -1484,7 +1484,9 @@ static int persist_check(vqcpc_vocoder *v) {
     if (flag != 0) {
         v->persist_pending = false;
         *(volatile unsigned *)v->abort_host = 0u;
-        vq_set_error("persistent decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete)");
+        v->persistent = 0;                 // e.g. the 64 workgroups could not all be resident: use the launch-per-step kernels from now on
+        vq_set_error("persistent decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete); "
+                     "this handle now uses the launch-per-step kernels (set_option persistent to re-enable)");
         return VQCPC_ERR_HIP;
     }
     return VQCPC_OK;
