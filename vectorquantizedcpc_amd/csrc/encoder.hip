@@ -445,17 +445,24 @@ __device__ __forceinline__ void vq_rows16(VqSmem &sm, int r0, int N, const float
         }
         vq_take(acc0, c0, e2[c0], x2, bd, bj);
     }
-    // first-index argmin: over the 16 codes of a lane group, then over the four waves (ascending codes)
+    // first-index argmin: over the 16 codes of a lane group, then over the four waves (ascending codes).  The lexicographic
+    // (distance, index) minimum is idempotent, so four DPP exchanges inside the row of 16 lanes (pairs, quads, the mirrored
+    // half, the mirrored row) leave it in every lane -- no ds_bpermute round trips.
+#define VQ_DPP_MIN(ctrl)                                                                                        \
+    {                                                                                                           \
+        const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd[r]), (ctrl), 0xF, 0xF, false)); \
+        const int oj = __builtin_amdgcn_update_dpp(0, bj[r], (ctrl), 0xF, 0xF, false);                          \
+        if (od < bd[r] || (od == bd[r] && oj < bj[r])) { bd[r] = od; bj[r] = oj; }                              \
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const float od = __shfl_xor(bd[r], off);
-            const int oj = __shfl_xor(bj[r], off);
-            if (od < bd[r] || (od == bd[r] && oj < bj[r])) { bd[r] = od; bj[r] = oj; }
-        }
+        VQ_DPP_MIN(0xB1)            // quad_perm [1,0,3,2]
+        VQ_DPP_MIN(0x4E)            // quad_perm [2,3,0,1]
+        VQ_DPP_MIN(0x141)           // row_half_mirror
+        VQ_DPP_MIN(0x140)           // row_mirror
         if ((lane & 15) == 0) { sm.cd[wave][4 * (lane >> 4) + r] = bd[r]; sm.cj[wave][4 * (lane >> 4) + r] = bj[r]; }
     }
+#undef VQ_DPP_MIN
     __syncthreads();
     if (tid < 16) {
         float d = sm.cd[0][tid];
