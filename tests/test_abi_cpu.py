@@ -96,3 +96,32 @@ def test_synth_is_deterministic():
     b = synth.encoder_state_dict()["encoder.2.weight"]
     assert torch.equal(a, b)
     assert abs(float(synth.mel("x", 2, 8).mean()) - 0.5) < 0.05
+
+
+def test_weight_slots_follow_the_module_without_state_dict():
+    """The native handles are keyed on (data_ptr, _version) of the weights, read per call through WeightSlots instead of
+    state_dict() (71 us vs 5 us): the slots must name exactly the reference's state_dict keys (minus the EMA buffers the
+    inference path never reads) and must see load_state_dict, dtype/device moves and buffer replacement."""
+    import copy
+
+    import torch
+
+    import vectorquantizedcpc_amd as V
+    from vectorquantizedcpc_amd import _lib, synth
+    enc = V.Encoder(V.ConfEncoder(80, 512, 512, 64, 256))
+    assert set(enc._WEIGHT_NAMES) == set(enc.state_dict()) - {"codebook.ema_count", "codebook.ema_weight"}
+    slots = _lib.WeightSlots(enc, enc._WEIGHT_NAMES)
+    k0 = _lib.WeightSlots.key(slots.tensors())
+    assert k0 == _lib.WeightSlots.key(slots.tensors())
+    enc.load_state_dict(synth.encoder_state_dict())                  # copy_ in place: versions move
+    k1 = _lib.WeightSlots.key(slots.tensors())
+    assert k1 != k0
+    enc.codebook.embedding = torch.zeros(512, 64)                    # a buffer REPLACED by assignment
+    k2 = _lib.WeightSlots.key(slots.tensors())
+    assert k2 != k1 and slots.tensors()[slots.names.index("codebook.embedding")] is enc.codebook.embedding
+    enc.double()                                                     # .to(): parameters keep identity, storage moves
+    assert _lib.WeightSlots.key(slots.tensors()) != k2
+    voc = V.Vocoder(V.ConfVocoder())
+    vs = _lib.WeightSlots(voc, list(voc.state_dict().keys()))
+    assert [t.shape for t in vs.tensors()] == [t.shape for t in voc.state_dict().values()]
+    assert "_slots" not in copy.deepcopy(enc).__dict__ and copy.deepcopy(enc).codebook._owner() is not enc
