@@ -196,6 +196,10 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * mixes of a sample step exchanged in-kernel -- when the dimensions are the reference's (size_h_rnn 896, size_h_fc 256);
  * 0 = always the launch-per-step kernels.  Both produce the same bits.  If an in-kernel exchange ever times out (1 s),
  * every workgroup leaves and the NEXT call on the handle (or vqcpc_vocoder_last_timing) returns VQCPC_ERR_HIP.
+ * fuse_fc2 (default 1): in calls of up to 4 utterance tiles (64 decode slots per tile group) the fc2 + draw of sample t-1
+ * and the GRU step of sample t share ONE launch -- W_hh h does not depend on the drawn sample, so it runs while the fc2
+ * workgroups of the same launch produce the candidates, which the GRU's gate waves then pick up through 8-byte granules.
+ * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) aborts like `persistent`.
  * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
  * use_graph: replay the per-sample kernels from a captured hipGraph
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
@@ -271,7 +275,8 @@ int vqcpc_loudness_normalize(vqcpc_loudness *m, float *wav, const int *lens, int
  * of the decode loop on the state the last generate()/logits() call left (HIP events on
  * `stream`; synchronises it).  out_us[5] = {GRU step, fc1, fc2 + draw, decode slots one launch
  * covers (a call of 33..80 or >= 192 utterances runs as two independent tile groups), which GRU-step
- * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel}.
+ * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel, 4 = the fused launch
+ * (fc2 + draw of the previous sample in front of the GRU step; out_us[2] is then fc2 as a launch of its own, for reference)}.
  * Each time includes this chip's ~1.5 us dependent-launch boundary. */
 int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 

@@ -259,7 +259,7 @@ def test_bench_kernel_32_utterances_direct_oracle():
     at 32 utterances x 480 samples, against the oracles directly."""
     voc, sd = vocoder()
     _check_rows_direct(voc, sd, 32, [0, 15, 16, 31, 7, 24], 480, seed=13, utt0=0, tag="d32")
-    assert voc.kernel_times(20)[4] == 1.0              # kernel kind of the call above: two tiles per workgroup
+    assert voc.kernel_times(20)[4] == 4.0              # kernel kind of the call above: the fused fc2 || GRU launch (two tiles)
 
 
 def test_large_batch_kernel_96_utterances_direct_oracle():
@@ -346,3 +346,30 @@ def test_persistent_single_utterance_decoder():
     assert stats[0][1] >= 0.999 * stats[0][0]
     with pytest.raises(RuntimeError):
         voc.kernel_times(10)               # no launch-per-step state after a persistent call
+
+
+def test_fused_fc2_gru_launch_same_bits_and_direct_oracle():
+    """Two launches per sample instead of three: the fc2 + draw of sample t-1 rides in front of the GRU step of sample t
+    and hands its candidates over in-kernel.  Same bits as the three-launch schedule at one tile, two tiles, two tile
+    groups and with continuous batching (slots reused by successive utterances), and the default (fused) path is checked
+    against the oracles directly in test_bench_kernel_32_utterances_direct_oracle."""
+    voc, _ = vocoder()
+    for B, slots in ((5, 0), (32, 0), (48, 0), (40, 20)):
+        z = synth.randint("fz/z%d" % B, (B, 3), 512).cuda()
+        spk = (torch.arange(B) * 3 % 102).cuda()
+        n_codes = [1 + (i % 3) for i in range(B)]
+        ids = list(range(500, 500 + B))
+        outs = []
+        try:
+            for fuse in (1, 0):
+                voc.set_option("fuse_fc2", fuse)
+                voc.set_option("slots", slots)
+                outs.append(voc.generate(z, spk, n_codes=n_codes, seed=77, utt_ids=ids, return_mulaw=True))
+        finally:
+            voc.set_option("fuse_fc2", 1)
+            voc.set_option("slots", 0)
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0]), (B, slots)
+        assert int((outs[0][1] != 0).sum()) > 100 * B
+    z = synth.randint("fz/one", (32, 2), 512).cuda()
+    voc.generate(z, (torch.arange(32) % 102).cuda(), seed=1, utt_base=0, max_steps=64)
+    assert voc.kernel_times(20)[4] == 4.0                   # the default path at 32 utterances is the fused launch

@@ -29,6 +29,7 @@ voc = V.Vocoder(V.ConfVocoder())
 voc.load_state_dict(synth.vocoder_state_dict())
 voc = voc.cuda().eval()
 voc.set_option("persistent", 0)            # the timeline is of the launch-per-step kernels
+voc.set_option("fuse_fc2", 0)              # ... one launch per kernel (the stamps are per kernel)
 z = synth.randint("timeline", (B, 4), 512).cuda()                     # 4 codes -> 1280 samples = 8 replays of 160
 spk = torch.arange(B, device="cuda") % 102
 voc.generate(z, spk, seed=13)

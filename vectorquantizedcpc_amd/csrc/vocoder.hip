@@ -335,8 +335,19 @@ struct ArModel {               // constant per handle (baked into the captured g
     int *cand_k;               // [Bpad][16] its class
     ArSlot *cur;               // [Sp] the slot row of the replay in flight (copied from ArCall::slots between
                                // replays): a fixed address, so the step kernels read it without first waiting for ArCall
+    // fused fc2 || GRU launch: candidates as 8-byte granules {(tag << 8 | class), score}, tag = step + 1, one 128-B
+    // line per producing workgroup: [tile][16 row groups][16 slots]
+    unsigned long long *candg;
+    unsigned *abort_dev;       // set when a candidate wait timed out: later steps stop waiting
+    unsigned *abort_host;      // the same, host-mapped: the next call on the handle reports it
+    int fused;                 // candidates live in candg (ar_finalize_kernel)
     int Hr, Hf, n_cls, upsample;
 };
+
+typedef unsigned long long u64;
+__device__ __forceinline__ unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned k0, unsigned k1, int w);
+__device__ __forceinline__ u64 ps_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ps_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The 16 row-group candidates of a decode slot (row groups are in class order): request, then
 // first-argmax, split so that the request can be issued early.  (A 4-lanes-per-slot variant that
@@ -392,11 +403,87 @@ __device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 
 // WAVE-SPECIALISED: the first NB waves (one per utterance tile in flight) chase the dependent loads of the
 // cell update (candidates -> x -> Gemb row; slot record, Gcond row, biases and old state at fixed addresses),
 // the next four run a branch-free load -> MFMA -> LDS stream over the four K quarters.
-template <int SW, int NB, int LEADP>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
-__global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
+// FUSED = 1: ONE launch carries fc2 + draw of step t-1 AND the GRU step t.  W_hh h_{t-1} -- the heavy part of the GRU step
+// -- does not depend on x_{t-1}, so it runs while the fc2 workgroups (the first n_fc2 blocks of the grid, so that they
+// are dispatched first) compute the candidates; only the gate waves wait, on 16 candidate granules per decode slot
+// ({tag = step, class, score}, written with agent-scope atomics, one 128-B line per producing workgroup: the data is the
+// flag, MI355X_MICROARCH.md "Valid forms" R2).  This takes the fc2 -> GRU kernel boundary (1.5 us) and fc2's whole body
+// (1.6 us after a cold start) off the critical path of a sample step.  Every wait is wall-clock bounded; a timeout sets
+// an abort word that makes every later wait of the call return at once, and the host reports it.
+// FUSED = 0 (teacher-forced scan, eager timing, > 4 tiles): candidates come from the previous launch's plain arrays.
+// fc2 over one 16-class row group + its Gumbel-max candidate per utterance, for local step `ts` (Hf = 256: SW = 4).
+// Used by ar_fc2_kernel (plain candidate arrays) and by the fused launch (granules).  All threads of the workgroup must
+// call it (two barriers); threads >= 256 only take part in those.
+template <int GRANULES>
+__device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restrict__ cp, int ts, int rg, int bt, int nbt,
+                                         float (*red)[16][17], float (*sc)[17]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool worker = tid < 256;
+    const int wv = worker ? wave : 0;
+    float4 wf[4], hv[4];
+    load_wfrag<4>(m.Wf_fc2, rg, 4, wv, lane, wf);
+    load_hfrag<4>(m.a1, m.Hf, bt, wv, lane, bt == nbt - 1 ? m.live_last : 16, hv);
+    const int rr = (tid >> 4) & 15, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;      // bg = decode slot
+    const float bias = m.b_fc2[cls];
+    __builtin_amdgcn_sched_barrier(0);
+    const ArCall c = *cp;
+    const int t = c.t_base + ts;
+    const ArSlot sl = m.cur[bg];
+    const int lt = t - sl.t0;
+    // noise of (class, utterance, sample) while the loads fly
+    const unsigned w = philox_word((unsigned)lt, sl.utt, (unsigned)(cls >> 2), (unsigned)c.seed,
+                                   (unsigned)(c.seed >> 32), cls & 3);
+    // 23 random bits + 0.5: every value is exact in fp32 and strictly inside (0, 1) -- a 24-bit form rounds to 1.0f
+    // at w >> 8 == 0xFFFFFF, i.e. +inf noise that wins whatever the logit is
+    const float g = -logf(-logf(((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f)));
+    const bool live = ts >= 0 && t < c.max_t && sl.row >= 0 && lt >= 0 && lt < sl.len;
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 acc = mfma_frag<4>(wf, hv);
+    if (worker) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    }
+    __syncthreads();
+    if (worker) {
+        float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
+        v += bias;
+        if (c.logits && live) c.logits[((size_t)sl.row * c.Ts + lt) * m.n_cls + cls] = v;
+        sc[rr][bb] = v + g;
+    }
+    __syncthreads();
+    if (tid < 16 && live) {
+        float best = sc[0][bb];
+        int k = 0;
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            if (sc[r][bb] > best) { best = sc[r][bb]; k = r; }
+        if (GRANULES) {
+            const unsigned tag = (unsigned)(t + 1) & 0xFFFFFFu;
+            ps_store(m.candg + ((size_t)(bt * 16 + rg) * 16 + bb), ((u64)((tag << 8) | (unsigned)(16 * rg + k)) << 32) | __float_as_uint(best));
+        } else {
+            m.cand_s[(size_t)bg * 16 + rg] = best;
+            m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
+        }
+    }
+}
+
+template <int SW, int NB, int LEADP, int FUSED>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
+__global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt,
+                                                               int n_fc2) {
     __shared__ float red[NB][4][16][17];
     __shared__ __attribute__((aligned(16))) float mt[256];            // mu-law decode table (row group 0 emits the samples)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, Hr = m.Hr;
+    __shared__ float sc[16][17];                                       // FUSED: scores of an fc2 workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, Hr = m.Hr;
+    int rg = blockIdx.x, pass = blockIdx.y;
+    if (FUSED) {
+        if ((int)blockIdx.x < n_fc2) {                                 // fc2 + draw of the PREVIOUS step
+            fc2_body<1>(m, cp, t_local - 1, blockIdx.x & 15, blockIdx.x >> 4, nbt, red[0], sc);
+            return;
+        }
+        const int gb = blockIdx.x - n_fc2;
+        rg = gb % (Hr >> 2);
+        pass = gb / (Hr >> 2);
+    }
     const size_t hsz = (size_t)nbt * Hr * 16;
     const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
     float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
@@ -411,7 +498,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
     // one pass of NB tiles per workgroup: grid.y = passes, so co-resident workgroups overlap one
     // pass's fragment loads with another's MFMAs when many utterances are in flight
     {
-        const int bt0 = blockIdx.y * NB;
+        const int bt0 = pass * NB;
         bool active = false, first = false;
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hold = 0.f;
         size_t hi = 0;
@@ -477,7 +564,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             // has a fixed address is requested up front -- candidates, slot record, call record, biases, old
             // state, the slot's Gcond row of this replay (gcur) -- so that only the Gemb row is a second level.
             Cand16 cd;
-            load_candidates16(m, sg, cd);
+            if (!FUSED) load_candidates16(m, sg, cd);
             const ArSlot sl = m.cur[sg];
             const ArCall c = *cp;
             const float4 bq = m.bh4[rg * 4 + u];
@@ -494,12 +581,46 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             active = bt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
             AR_STAMP(tid == 0 && (active || !active), 0, 4);
             first = lt == 0;
+            int xf = 0;
+            if (FUSED) {
+                // wait for the 16 candidates of this slot (step t-1's draw, tag t) from the fc2 workgroups of THIS launch
+                // (or, at the first step of a replay, of the trailing fc2 launch of the previous one)
+                const bool need = active && !first;
+                const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
+                const unsigned tag = (unsigned)t & 0xFFFFFFu;
+                u64 gv[16];
+                const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                bool gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                for (unsigned spins = 0; !gave_up; ++spins) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        gv[q] = ps_load(cg + q * 16);
+                        ok &= (unsigned)(gv[q] >> 40) == tag;
+                    }
+                    if (__all(ok || !need)) break;
+                    if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {      // 0.25 s
+                        if (lane == 0) {
+                            __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        gave_up = true;
+                    }
+                }
+                float best = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                               // row groups are in class order: first argmax
+                    const float sq = __uint_as_float((unsigned)gv[q]);
+                    if (!gave_up && sq > best) { best = sq; xf = (int)((gv[q] >> 32) & 255u); }
+                }
+            }
             if (active) {
                 int x;
                 if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
                 else if (first) x = m.n_cls / 2;
                 else {
-                    x = merge_candidates16(cd);
+                    if (!FUSED) x = merge_candidates16(cd);
+                    else x = xf;
                     emit = rg == 0 && u == 0;                   // sample lt-1 goes out after the barrier
                     if (emit) { wavp = c.wav ? c.wav + (size_t)sl.row * c.Lout + lt - 1 : nullptr;
                                 mulp = c.mulaw ? c.mulaw + (size_t)sl.row * c.Lout + lt - 1 : nullptr; xraw = x; }
@@ -738,50 +859,14 @@ __device__ __forceinline__ unsigned philox_word(unsigned c0, unsigned c1, unsign
     return w == 0 ? c[0] : w == 1 ? c[1] : w == 2 ? c[2] : c[3];
 }
 
-// fc2 over one 16-class row group + its Gumbel-max candidate per utterance.  Hf = 256: SW = 4.
+// fc2 + draw as a launch of its own (plain candidate arrays; GRANULES = 1: the trailing launch of a fused replay).
+template <int GRANULES>
 __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
     __shared__ float red[4][16][17];
     __shared__ float sc[16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
-    AR_STAMP(tid == 0, 2, 0);
-    float4 wf[4], hv[4];
-    load_wfrag<4>(m.Wf_fc2, rg, 4, wave, lane, wf);
-    load_hfrag<4>(m.a1, m.Hf, bt, wave, lane, bt == (int)gridDim.y - 1 ? m.live_last : 16, hv);
-    const int rr = tid >> 4, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;      // bg = decode slot
-    const float bias = m.b_fc2[cls];
-    __builtin_amdgcn_sched_barrier(0);
-    const ArCall c = *cp;
-    const int t = c.t_base + t_local;
-    const ArSlot sl = m.cur[bg];
-    const int lt = t - sl.t0;
-    // noise of (class, utterance, sample) while the loads fly
-    const unsigned w = philox_word((unsigned)lt, sl.utt, (unsigned)(cls >> 2), (unsigned)c.seed,
-                                   (unsigned)(c.seed >> 32), cls & 3);
-    // 23 random bits + 0.5: every value is exact in fp32 and strictly inside (0, 1) -- a 24-bit form rounds to 1.0f
-    // at w >> 8 == 0xFFFFFF, i.e. +inf noise that wins whatever the logit is
-    const float g = -logf(-logf(((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f)));
-    const bool live = t < c.max_t && sl.row >= 0 && lt < sl.len;
-    __builtin_amdgcn_sched_barrier(0);
-    const f32x4 acc = mfma_frag<4>(wf, hv);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-    AR_STAMP(tid == 0, 2, 1);
-    __syncthreads();
-    float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
-    v += bias;
-    if (c.logits && live) c.logits[((size_t)sl.row * c.Ts + lt) * m.n_cls + cls] = v;
-    sc[rr][bb] = v + g;
-    __syncthreads();
-    if (tid < 16 && live) {
-        float best = sc[0][bb];
-        int k = 0;
-#pragma unroll
-        for (int r = 1; r < 16; ++r)
-            if (sc[r][bb] > best) { best = sc[r][bb]; k = r; }
-        m.cand_s[(size_t)bg * 16 + rg] = best;
-        m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
-    }
-    AR_STAMP(tid == 0, 2, 3);
+    AR_STAMP(threadIdx.x == 0, 2, 0);
+    fc2_body<GRANULES>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc);
+    AR_STAMP(threadIdx.x == 0, 2, 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -809,7 +894,6 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
 // Every spin is bounded (wall clock); a timeout raises an abort flag that every workgroup polls, and all waves leave.
 // ------------------------------------------------------------------------------------------
 #define PS_NB 64
-typedef unsigned long long u64;
 // Timeline stamps of workgroup PS_STAMP_BLK (100 MHz wall clock), steps 256..383, for tools/persist_timeline.py: compiled
 // in only with -DVQCPC_PS_STAMPS (a debug build under build/stamps/, never the shipped library).
 #ifdef VQCPC_PS_STAMPS
@@ -841,8 +925,6 @@ __device__ __forceinline__ void ps_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ u64 ps_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ps_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // index of h[k] in the LDS copy: inside each 16-block, [component k % 4][k / 4 % 4], so that a chain reads the four
 // k of one MFMA as one 16-byte LDS word
 __device__ __forceinline__ int ps_perm(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -1185,11 +1267,25 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
     if (sl.row < 0) return;
     const int end = sl.t0 + sl.len;
     if (end <= c.t_base || end > c.t_base + c.S) return;
-    float best = m.cand_s[(size_t)sg * 16];
-    int x = m.cand_k[(size_t)sg * 16];
-    for (int q = 1; q < 16; ++q) {
-        const float sc = m.cand_s[(size_t)sg * 16 + q];
-        if (sc > best) { best = sc; x = m.cand_k[(size_t)sg * 16 + q]; }
+    float best;
+    int x;
+    if (m.fused) {
+        const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
+        u64 gq = ps_load(cg);
+        best = __uint_as_float((unsigned)gq);
+        x = (int)((gq >> 32) & 255u);
+        for (int q = 1; q < 16; ++q) {
+            gq = ps_load(cg + q * 16);
+            const float sc = __uint_as_float((unsigned)gq);
+            if (sc > best) { best = sc; x = (int)((gq >> 32) & 255u); }
+        }
+    } else {
+        best = m.cand_s[(size_t)sg * 16];
+        x = m.cand_k[(size_t)sg * 16];
+        for (int q = 1; q < 16; ++q) {
+            const float sc = m.cand_s[(size_t)sg * 16 + q];
+            if (sc > best) { best = sc; x = m.cand_k[(size_t)sg * 16 + q]; }
+        }
     }
     if (c.wav) c.wav[(size_t)sl.row * c.Lout + sl.len - 1] = m.mulaw_tab[x];
     if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + sl.len - 1] = x;
@@ -1280,9 +1376,9 @@ struct vqcpc_vocoder {
     // step overlaps the other's fc1/fc2; there is no edge between them inside a graph.
     struct Group {
         ArCall *call = nullptr;          // device
-        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur;
+        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur, candg;   // candg: candidate granules + the abort word behind them
         std::map<int, hipGraphExec_t> graphs;   // key: (tiles in the group, live columns of the last tile, lead6)
-        const void *baked[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
+        const void *baked[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
     } grp[2];
     int two_groups = 1;                  // 0 = always one group
     hipStream_t side_stream = nullptr;
@@ -1293,6 +1389,7 @@ struct vqcpc_vocoder {
     unsigned *abort_host = nullptr;      // its abort flag: pinned host memory the kernel writes and the host reads without a HIP call
     HostStage stage;
     float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
+    int fuse_fc2 = 1;                    // calls of up to 4 tiles: fc2 of step t-1 and the GRU step t share one launch
     int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
     bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
@@ -1320,7 +1417,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     for (auto &g : v->grp) {
         for (auto &kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
         if (g.call) (void)hipFree(g.call);
-        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur};
+        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur, &g.candg};
         for (DevBuf *b : gb) b->release();
     }
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
@@ -1458,6 +1555,11 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         return VQCPC_OK;
     }
     if (!strcmp(name, "two_groups")) { v->two_groups = value != 0; return VQCPC_OK; }
+    if (!strcmp(name, "fuse_fc2")) {
+        if ((value != 0) != (v->fuse_fc2 != 0)) clear_graphs(v);
+        v->fuse_fc2 = value != 0;
+        return VQCPC_OK;
+    }
     if (!strcmp(name, "persistent")) {
         VQ_REQUIRE(value >= -1 && value <= 1, "persistent must be -1 (auto), 0 or 1");
         v->persistent = value;
@@ -1477,6 +1579,7 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
     return VQCPC_ERR_INVALID;
 }
 
+static void clear_graphs(vqcpc_vocoder *v);
 // After the stream that carried a persistent decode has been synchronised: did an in-kernel exchange time out?
 static int persist_check(vqcpc_vocoder *v) {
     if (!v->persist_pending) return VQCPC_OK;
@@ -1484,9 +1587,10 @@ static int persist_check(vqcpc_vocoder *v) {
     if (flag != 0) {
         v->persist_pending = false;
         *(volatile unsigned *)v->abort_host = 0u;
-        v->persistent = 0;                 // e.g. the 64 workgroups could not all be resident: use the launch-per-step kernels from now on
-        vq_set_error("persistent decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete); "
-                     "this handle now uses the launch-per-step kernels (set_option persistent to re-enable)");
+        v->persistent = 0;                 // e.g. the workgroups could not all be resident: no in-kernel exchanges from now on
+        if (v->fuse_fc2) { v->fuse_fc2 = 0; clear_graphs(v); }
+        vq_set_error("decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete); this handle now "
+                     "uses one launch per kernel and step (set_option persistent / fuse_fc2 to re-enable)");
         return VQCPC_ERR_HIP;
     }
     return VQCPC_OK;
@@ -1547,13 +1651,21 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
         }
         v->big_attr_set = true;
     }
+    // Fused schedule (m.fused): step i = { fc2 of step i-1  ||  GRU of step i } in ONE launch, then fc1 of step i; the
+    // fc2 of the replay's last step runs as a trailing launch (before the slot records change), so the first launch of a
+    // replay carries no fc2 blocks.
+    const int rgs = v->d.Hr / 4, npass = (nbt + 1) / 2;
     for (int i = 0; i < n; ++i) {
+        const int nf = (m.fused && i > 0) ? (v->d.n_cls / 16) * nbt : 0;
         switch (SW) {
 #define CASE(k) case k: \
-            if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt); \
+            if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, nf); \
+            else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, nf); \
+            else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, nf); \
+            else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0); \
             else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt); \
-            else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
-            else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt); \
+            else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0); \
+            else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0); \
             if (tf) break; \
             if (nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
             else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
@@ -1562,8 +1674,9 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
 #undef CASE
             default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
         }
-        if (!tf) hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
+        if (!tf && !m.fused) hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
     }
+    if (!tf && m.fused) hipLaunchKernelGGL(ar_fc2_kernel<1>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, n - 1);
     if (!tf) hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, call, n);
     hipLaunchKernelGGL(ar_next_row_kernel, dim3(nbt * 16), dim3(256), 0, s, m, (const ArCall *)call);
@@ -1674,14 +1787,15 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
+    unsigned *abort_dev_ptr = nullptr;       // device view of the host-mapped abort flag (in-kernel waits that time out)
+    HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev_ptr, v->abort_host, 0));
     // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
     if (v->persistent != 0 && B == 1 && !inputs && Hr == 896 && d.Hf == 256 && d.n_cls == 256 && lens[Bp] > 0 &&
         lens[Bp] < (1 << 24)) {
         const size_t ngr = (size_t)3 * PS_NB * PS_PAD;       // h_t, a_t, candidates: one 128-B line per workgroup each
         TRY(v->px.reserve(ngr * sizeof(u64)));
         HIP_TRY(hipMemsetAsync(v->px.p, 0, ngr * sizeof(u64), s));
-        unsigned *abort_dev = nullptr;
-        HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev, v->abort_host, 0));
+        unsigned *abort_dev = abort_dev_ptr;
         PersistP pp{};
         pp.w_hh = v->w_hh; pp.w_fc1 = v->w_fc1; pp.b_fc1 = v->b_fc1; pp.w_fc2 = v->w_fc2; pp.b_fc2 = v->b_fc2;
         pp.Gemb4 = v->Gemb4; pp.bh4 = v->bh4; pp.Gcond = v->gcond.as<float>(); pp.mulaw_tab = v->mulaw_tab;
@@ -1713,6 +1827,9 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         HIP_TRY(hipMemsetAsync(G.har.p, 0, 2 * hsz, s));
         HIP_TRY(hipMemsetAsync(G.cand_s.p, 0, (size_t)Spg * 16 * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(G.cand_k.p, 0, (size_t)Spg * 16 * sizeof(int), s));
+        const size_t cg_bytes = (size_t)nb * 16 * 16 * sizeof(u64);          // granules, then one 64-byte block for the abort word
+        TRY(G.candg.reserve(cg_bytes + 64));
+        HIP_TRY(hipMemsetAsync(G.candg.p, 0, cg_bytes + 64, s));
         ArCall &c = calls[g];
         c = ArCall{};
         c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
@@ -1737,6 +1854,14 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
             m.live_last = live < 1 ? 1 : (live > 16 ? 16 : live);
         }
         m.lead6 = n_grp == 2 && nb <= 2;
+        m.candg = G.candg.as<u64>();
+        m.abort_dev = (unsigned *)((char *)G.candg.p + cg_bytes);
+        m.abort_host = abort_dev_ptr;
+        {
+            const size_t big_lds = (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
+            const bool big = v->big_min_tiles > 0 && nb >= v->big_min_tiles && Hr % 16 == 0 && big_lds <= 160 * 1024;
+            m.fused = v->fuse_fc2 && !tf && !big && nb <= 4 && gmax[g] < (1 << 24);
+        }
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
     for (int g = 0; g < n_grp; ++g)       // replay 0's slot row and Gcond rows
@@ -1748,13 +1873,13 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         for (int g = 0; g < n_grp; ++g) {
             auto &G = v->grp[g];
             // a graph bakes its ArModel (buffer pointers): drop cached graphs if a workspace moved
-            const void *now[6] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p};
+            const void *now[7] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p, G.candg.p};
             if (memcmp(G.baked, now, sizeof now) != 0) {
                 for (auto &kv : G.graphs) (void)hipGraphExecDestroy(kv.second);
                 G.graphs.clear();
                 memcpy(G.baked, now, sizeof now);
             }
-            const int gkey = ((tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6) * 2 + (tf ? 1 : 0);   // what the capture bakes
+            const int gkey = (((tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6) * 2 + (tf ? 1 : 0)) * 2 + models[g].fused;   // what the capture bakes
             auto it = G.graphs.find(gkey);
             if (it == G.graphs.end()) {
                 hipGraph_t gr = nullptr;
@@ -1800,6 +1925,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     HIP_TRY(hipEventRecord(v->ev1, s));
     v->last_steps = max_t;
     v->last_call = calls[0]; v->last_model = models[0]; v->have_last = true;
+    if (models[0].fused) v->persist_pending = true;      // an in-kernel candidate wait may report a timeout
     return VQCPC_OK;
 }
 
@@ -1839,18 +1965,22 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     const dim3 blk(256);
     const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
+    const int nf = (v->d.n_cls / 16) * c.nbt;            // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
             if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
             const int n = pass == 0 ? 20 : reps;
             for (int i = 0; i < n; ++i) {
-                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
+                if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    if (which == 0 && m.fused && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    else if (which == 0 && m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    else if (which == 0 && m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    else if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
                     else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt); \
-                    else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
-                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
+                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
                     else if (c.nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     break;
@@ -1867,7 +1997,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
         out_us[which] = ms * 1e3f / (float)reps;
     }
     out_us[3] = (float)(c.nbt * 16);       // decode slots one launch of the timed configuration covers
-    out_us[4] = c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f);    // which GRU-step kernel that configuration runs
+    out_us[4] = m.fused ? 4.f : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
     return VQCPC_OK;
 }
 
