@@ -414,12 +414,14 @@ __device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 
 // fc2 over one 16-class row group + its Gumbel-max candidate per utterance, for local step `ts` (Hf = 256: SW = 4).
 // Used by ar_fc2_kernel (plain candidate arrays) and by the fused launch (granules).  All threads of the workgroup must
 // call it (two barriers); threads >= 256 only take part in those.
+// `tid` = index inside the 256-thread team that computes (rg, bt); `worker` = false for threads that only keep the
+// workgroup's barriers company (the tail of a 320/384-thread block, teams past the last (rg, bt) of a 1024-thread block).
 template <int GRANULES>
 __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restrict__ cp, int ts, int rg, int bt, int nbt,
-                                         float (*red)[16][17], float (*sc)[17]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool worker = tid < 256;
+                                         float (*red)[16][17], float (*sc)[17], int tid, bool worker) {
+    const int lane = tid & 63, wave = (tid >> 6) & 3;
     const int wv = worker ? wave : 0;
+    if (!worker) { rg = 0; bt = 0; }
     float4 wf[4], hv[4];
     load_wfrag<4>(m.Wf_fc2, rg, 4, wv, lane, wf);
     load_hfrag<4>(m.a1, m.Hf, bt, wv, lane, bt == nbt - 1 ? m.live_last : 16, hv);
@@ -451,7 +453,7 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
         sc[rr][bb] = v + g;
     }
     __syncthreads();
-    if (tid < 16 && live) {
+    if (worker && tid < 16 && live) {
         float best = sc[0][bb];
         int k = 0;
 #pragma unroll
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
     int rg = blockIdx.x, pass = blockIdx.y;
     if (FUSED) {
         if ((int)blockIdx.x < n_fc2) {                                 // fc2 + draw of the PREVIOUS step
-            fc2_body<1>(m, cp, t_local - 1, blockIdx.x & 15, blockIdx.x >> 4, nbt, red[0], sc);
+            fc2_body<1>(m, cp, t_local - 1, blockIdx.x & 15, blockIdx.x >> 4, nbt, red[0], sc, tid, tid < 256);
             return;
         }
         const int gb = blockIdx.x - n_fc2;
@@ -686,14 +688,30 @@ __device__ __forceinline__ void big_stage_store(float4 *dst, int t4, int tid, co
     }
 }
 
-template <int SW>
-__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
+// FUSED = 1: as in ar_gru_kernel, the first n_fc2 blocks of the launch run fc2 + draw of the PREVIOUS step and the
+// cell-update waves pick the candidates up through granules -- after the staging barriers, while the MFMA waves compute.
+template <int SW, int FUSED>
+__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Hr = m.Hr;
     float4 *hs = (float4 *)smem;                                             // [2][Hr*4] float4 = two state tiles
     float (*red)[3][4][16][17] = (float (*)[3][4][16][17])(smem + (size_t)2 * Hr * 16 * sizeof(float));   // [tile][gate][kq][unit][slot]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int blk = blockIdx.x, bt0 = blockIdx.y * 2, nb = nbt - bt0 < 2 ? nbt - bt0 : 2;
+    int blk = blockIdx.x, passy = blockIdx.y;
+    if (FUSED) {
+        if ((int)blockIdx.x < n_fc2) {
+            // four 256-thread teams per workgroup, one (row group, tile) each: 4 nbt fc2 workgroups in front of the GRU ones
+            const int team = tid >> 8, pair = blockIdx.x * 4 + team;
+            char *base = smem + (size_t)team * (5 * 16 * 17 * sizeof(float));
+            fc2_body<1>(m, cp, t_local - 1, pair & 15, pair >> 4, nbt, (float (*)[16][17])base,
+                        (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, pair < 16 * nbt);
+            return;
+        }
+        const int gb = blockIdx.x - n_fc2;
+        blk = gb % (Hr >> 4);
+        passy = gb / (Hr >> 4);
+    }
+    const int bt0 = passy * 2, nb = nbt - bt0 < 2 ? nbt - bt0 : 2;
     const size_t hsz = (size_t)nbt * Hr * 16;
     const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
     float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
         float *hallp = nullptr;
         // first level of the operand chain: everything with a fixed address (as in ar_gru_kernel)
         Cand16 cd;
-        load_candidates16(m, sg, cd);
+        if (!FUSED) load_candidates16(m, sg, cd);
         const ArSlot sl = m.cur[sg];
         const ArCall c = *cp;
 #pragma unroll
@@ -733,12 +751,48 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
         const int lt = t - sl.t0;
         const bool active = gbt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
         const bool first = lt == 0;
+        int xf = 0;
+        if (FUSED) {                                             // this wave's share of the staging first: the MFMA waves
+            big_stage_store(hs, t4, tid, st);                    // must not wait behind the candidate hand-off
+            __syncthreads();
+            big_stage_load(src + t4, t4, tid, nb > 1, st);
+            big_stage_store(hs + t4, t4, tid, st);
+            __syncthreads();
+            const bool need = active && !first;
+            const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
+            const unsigned tag = (unsigned)t & 0xFFFFFFu;
+            u64 gv[16];
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            bool gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            for (unsigned spins = 0; !gave_up; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) {
+                    gv[qq] = ps_load(cg + qq * 16);
+                    ok &= (unsigned)(gv[qq] >> 40) == tag;
+                }
+                if (__all(ok || !need)) break;
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {      // 0.25 s
+                    if (lane == 0) {
+                        __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    gave_up = true;
+                }
+            }
+            float best = -INFINITY;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+                const float sq = __uint_as_float((unsigned)gv[qq]);
+                if (!gave_up && sq > best) { best = sq; xf = (int)((gv[qq] >> 32) & 255u); }
+            }
+        }
         if (active) {
             int x;
             if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
             else if (first) x = m.n_cls / 2;
             else {
-                x = merge_candidates16(cd);
+                x = FUSED ? xf : merge_candidates16(cd);
                 if (blk == 0 && uh == 0 && u == 0) {             // emit sample lt-1 (network_vocoder.py:78 output)
                     if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
                     if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
@@ -758,11 +812,13 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
             }
             if (c.hall) hallp = c.hall + ((size_t)sl.row * c.CH + (lt - c.hall_t0)) * Hr + 16 * blk + 8 * uh + u;
         }
-        big_stage_store(hs, t4, tid, st);
-        __syncthreads();
-        big_stage_load(src + t4, t4, tid, nb > 1, st);
-        big_stage_store(hs + t4, t4, tid, st);
-        __syncthreads();
+        if (!FUSED) {
+            big_stage_store(hs, t4, tid, st);
+            __syncthreads();
+            big_stage_load(src + t4, t4, tid, nb > 1, st);
+            big_stage_store(hs + t4, t4, tid, st);
+            __syncthreads();
+        }
         __syncthreads();
         if (active) {
 #pragma unroll
@@ -865,7 +921,7 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     __shared__ float red[4][16][17];
     __shared__ float sc[16][17];
     AR_STAMP(threadIdx.x == 0, 2, 0);
-    fc2_body<GRANULES>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc);
+    fc2_body<GRANULES>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc, threadIdx.x, true);
     AR_STAMP(threadIdx.x == 0, 2, 3);
 }
 
@@ -1644,7 +1700,8 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     const bool big = v->big_min_tiles > 0 && nbt >= v->big_min_tiles && v->d.Hr % 16 == 0 && big_lds <= 160 * 1024;
     if (big && !v->big_attr_set) {
         switch (SW) {
-#define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
+#define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
+                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
             default: break;
@@ -1656,14 +1713,15 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     // replay carries no fc2 blocks.
     const int rgs = v->d.Hr / 4, npass = (nbt + 1) / 2;
     for (int i = 0; i < n; ++i) {
-        const int nf = (m.fused && i > 0) ? (v->d.n_cls / 16) * nbt : 0;
+        const int nf = (m.fused && i > 0) ? (big ? (v->d.n_cls / 16) * nbt / 4 : (v->d.n_cls / 16) * nbt) : 0;
         switch (SW) {
 #define CASE(k) case k: \
-            if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, nf); \
+            if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, nf); \
+            else if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, nf); \
             else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, nf); \
             else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, nf); \
             else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0); \
-            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt); \
+            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0); \
             else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0); \
             else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0); \
             if (tf) break; \
@@ -1746,7 +1804,11 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // group of 32 -- the chip retires only ~0.43 dependent launches per us across queues -- while
     // 2 x 32 runs at 14.5 us per sample against 17.3 us for one group of 64.)
     const bool tf = inputs != nullptr;     // teacher-forced scan: one group, GRU steps only, chunked GEMMs for fc1 / fc2
-    const bool split = !tf && v->two_groups && v->use_graph && nbt >= 3 &&
+    // With the fused fc2 || GRU launch the overlap two groups were for happens inside one launch, and two fused launches in
+    // flight only compete (64 utterances: 17.4 us per step on two groups, 13.4 on one: profiles/r02_gru_variants.csv): the
+    // small kernel runs as ONE group; only large-batch calls of >= 2 * big_min_tiles tiles are still split.
+    const bool small_fused = v->fuse_fc2 && !(v->big_min_tiles > 0 && nbt >= v->big_min_tiles);
+    const bool split = !tf && v->two_groups && v->use_graph && nbt >= 3 && !small_fused &&
                        !(v->big_min_tiles > 0 && nbt >= v->big_min_tiles && nbt < 2 * v->big_min_tiles);
     const int n_grp = split ? 2 : 1;
     const int tiles[2] = {split ? (nbt + 1) / 2 : nbt, split ? nbt / 2 : 0};
@@ -1860,7 +1922,8 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         {
             const size_t big_lds = (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
             const bool big = v->big_min_tiles > 0 && nb >= v->big_min_tiles && Hr % 16 == 0 && big_lds <= 160 * 1024;
-            m.fused = v->fuse_fc2 && !tf && !big && nb <= 4 && gmax[g] < (1 << 24);
+            (void)big;
+            m.fused = v->fuse_fc2 && !tf && gmax[g] < (1 << 24);
         }
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
@@ -1965,7 +2028,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     const dim3 blk(256);
     const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
-    const int nf = (v->d.n_cls / 16) * c.nbt;            // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
+    const int nf = tbig ? (v->d.n_cls / 16) * c.nbt / 4 : (v->d.n_cls / 16) * c.nbt;   // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
             if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
@@ -1974,11 +2037,12 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                 if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0 && m.fused && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
-                    else if (which == 0 && m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
-                    else if (which == 0 && m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    if (which == 0 && m.fused && !tbig && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    else if (which == 0 && m.fused && !tbig && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    else if (which == 0 && m.fused && !tbig) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
                     else if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
-                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt); \
+                    else if (which == 0 && tbig && m.fused) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 1, c.nbt, nf); \
+                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt, 0); \
                     else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
                     else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
                     else if (c.nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
