@@ -275,8 +275,9 @@ int vqcpc_loudness_normalize(vqcpc_loudness *m, float *wav, const int *lens, int
  * of the decode loop on the state the last generate()/logits() call left (HIP events on
  * `stream`; synchronises it).  out_us[5] = {GRU step, fc1, fc2 + draw, decode slots one launch
  * covers (a call of 33..80 or >= 192 utterances runs as two independent tile groups), which GRU-step
- * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel, 4 = the fused launch
- * (fc2 + draw of the previous sample in front of the GRU step; out_us[2] is then fc2 as a launch of its own, for reference)}.
+ * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel; 4 / 5 = the fused launch
+ * (fc2 + draw of the previous sample in front of the GRU step) on the small / the large-batch kernel -- out_us[2] is then
+ * fc2 as a launch of its own, for reference}.
  * Each time includes this chip's ~1.5 us dependent-launch boundary. */
 int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 

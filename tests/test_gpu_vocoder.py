@@ -266,7 +266,7 @@ def test_large_batch_kernel_96_utterances_direct_oracle():
     """ar_gru_big_kernel (6 tiles: LDS-staged state, full 16-row gate tiles) against the oracles directly."""
     voc, sd = vocoder()
     _check_rows_direct(voc, sd, 96, [0, 17, 47, 64, 95], 480, seed=5, utt0=200, tag="d96")
-    assert voc.kernel_times(20)[4] == 2.0
+    assert voc.kernel_times(20)[4] == 5.0              # the fused fc2 || large-batch GRU launch
 
 
 def test_two_tile_groups_48_utterances_direct_oracle():

@@ -2061,7 +2061,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
         out_us[which] = ms * 1e3f / (float)reps;
     }
     out_us[3] = (float)(c.nbt * 16);       // decode slots one launch of the timed configuration covers
-    out_us[4] = m.fused ? 4.f : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
+    out_us[4] = m.fused ? (tbig ? 5.f : 4.f) : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
     return VQCPC_OK;
 }
 
