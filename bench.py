@@ -312,7 +312,8 @@ def gru_roofline(voc, n_utt, step_us):
     flop = 2.0 * (GRU_MAC + (65536 if fused else 0)) * per_launch
     achieved = flop / (gru_us * 1e-6) / 1e12
     # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
-    alg_bytes = 4.0 * (GRU_MAC + per_launch * (2 * 896 + 2 * 3 * 896))
+    # (+ W_fc2 once and the fc1 outputs per utterance when fc2 rides in the same launch)
+    alg_bytes = 4.0 * (GRU_MAC + per_launch * (2 * 896 + 2 * 3 * 896)) + (4.0 * (65536 + per_launch * 256) if fused else 0.0)
     return {"bound": "mfma", "kernel": names.get(int(kind), "ar_gru") + ": W_hh h for all utterances + GRU cell update",
             "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "flop_per_launch": flop,
