@@ -307,21 +307,26 @@ def gru_roofline(voc, n_utt, step_us):
     names = {0: "ar_gru_kernel<14,1> (one tile)", 1: "ar_gru_kernel<14,2> (two tiles per workgroup)",
              2: "ar_gru_big_kernel<14> (LDS-staged state, full 16-row gate tiles)",
              4: "ar_gru_kernel<14,.,.,fused> (ONE launch: fc2 + draw of sample t-1 in front of the GRU step of sample t)",
-             5: "ar_gru_big_kernel<14,fused> (ONE launch: fc2 + draw of sample t-1 in front of the large-batch GRU step of sample t)"}
-    fused = int(kind) in (4, 5)
-    flop = 2.0 * (GRU_MAC + (65536 if fused else 0)) * per_launch
+             5: "ar_gru_big_kernel<14,fused> (ONE launch: fc2 + draw of sample t-1 in front of the large-batch GRU step of sample t)",
+             6: "ar_gru_kernel<14,.,.,2> (the whole sample step in ONE launch: fc1 and fc2 + draw of sample t-1 in front of the GRU step of sample t)",
+             7: "ar_gru_big_kernel<14,2> (the whole sample step in ONE launch, large-batch GRU kernel)"}
+    fused = int(kind) in (4, 5, 6, 7)
+    whole = int(kind) in (6, 7)
+    flop = 2.0 * (GRU_MAC + (65536 if fused else 0) + (229376 if whole else 0)) * per_launch
     achieved = flop / (gru_us * 1e-6) / 1e12
     # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance
     # (+ W_fc2 once and the fc1 outputs per utterance when fc2 rides in the same launch)
-    alg_bytes = 4.0 * (GRU_MAC + per_launch * (2 * 896 + 2 * 3 * 896)) + (4.0 * (65536 + per_launch * 256) if fused else 0.0)
+    alg_bytes = (4.0 * (GRU_MAC + per_launch * (2 * 896 + 2 * 3 * 896)) + (4.0 * (65536 + per_launch * 256) if fused else 0.0) +
+                 (4.0 * 229376 if whole else 0.0))
     return {"bound": "mfma", "kernel": names.get(int(kind), "ar_gru") + ": W_hh h for all utterances + GRU cell update",
             "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "flop_per_launch": flop,
             "avg_launch_us": gru_us, "utterances_per_launch": per_launch,
             "how": "HIP events on the launch stream around 2000 back-to-back launches (includes the ~1.5 us "
                    "dependent-launch boundary)",
-            "launches_per_sample": 2 if fused else 3,
-            "other_kernels_us": {"ar_fc1_kernel": fc1_us, "ar_fc2_kernel" + (" (as its own launch, not on the fused path)" if fused else ""): fc2_us},
+            "launches_per_sample": 1 if whole else (2 if fused else 3),
+            "other_kernels_us": {"ar_fc1_kernel" + (" (as its own launch, not on the fused path)" if whole else ""): fc1_us,
+                                 "ar_fc2_kernel" + (" (as its own launch, not on the fused path)" if fused else ""): fc2_us},
             "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
                             "flop": FLOP_PER_SAMPLE * n_utt,
                             "how": "HIP events around the whole decode loop / samples per utterance"}}

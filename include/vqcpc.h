@@ -200,6 +200,8 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * and the GRU step of sample t share ONE launch -- W_hh h does not depend on the drawn sample, so it runs while the fc2
  * workgroups of the same launch produce the candidates, which the GRU's gate waves then pick up through 8-byte granules.
  * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) aborts like `persistent`.
+ * fuse_fc1 (default 1, needs fuse_fc2): fc1 of sample t-1 rides in the same launch as well -- it reads the state the
+ * previous launch wrote and hands its outputs to the fc2 teams as granules: ONE launch per sample.
  * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
  * use_graph: replay the per-sample kernels from a captured hipGraph
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
@@ -276,8 +278,8 @@ int vqcpc_loudness_normalize(vqcpc_loudness *m, float *wav, const int *lens, int
  * `stream`; synchronises it).  out_us[5] = {GRU step, fc1, fc2 + draw, decode slots one launch
  * covers (a call of 33..80 or >= 192 utterances runs as two independent tile groups), which GRU-step
  * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel; 4 / 5 = the fused launch
- * (fc2 + draw of the previous sample in front of the GRU step) on the small / the large-batch kernel -- out_us[2] is then
- * fc2 as a launch of its own, for reference}.
+ * (fc2 + draw of the previous sample in front of the GRU step) on the small / the large-batch kernel; 6 / 7 = the whole
+ * sample step in one launch (fc1 too) -- out_us[1] / out_us[2] are then fc1 / fc2 as launches of their own, for reference}.
  * Each time includes this chip's ~1.5 us dependent-launch boundary. */
 int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 

@@ -94,8 +94,10 @@ def main():
     hit, miss = res[(kern, "TCC_HIT_sum")][1], res[(kern, "TCC_MISS_sum")][1]
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
     alg = 4.0 * (2408448 + args.utterances * (2 * 896 + 2 * 3 * 896))
-    if ", 1>" in kern:                 # fused launch: fc2 + draw of the previous sample rides along (W_fc2 once, fc1 outputs per utterance)
+    if ", 1>" in kern or ", 2>" in kern:   # fused launch: fc2 + draw of the previous sample rides along (W_fc2 once, fc1 outputs per utterance)
         alg += 4.0 * (65536 + args.utterances * 256)
+    if ", 2>" in kern:                    # ... and fc1 (W_fc1 once; the state it reads is the one the GRU reads)
+        alg += 4.0 * 229376
     out = {"kernel": kern, "utterances": args.utterances, "launch_mode": args.mode,
            "dispatches_averaged": res[(kern, "FETCH_SIZE")][0],
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,

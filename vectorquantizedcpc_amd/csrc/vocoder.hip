@@ -338,9 +338,11 @@ struct ArModel {               // constant per handle (baked into the captured g
     // fused fc2 || GRU launch: candidates as 8-byte granules {(tag << 8 | class), score}, tag = step + 1, one 128-B
     // line per producing workgroup: [tile][16 row groups][16 slots]
     unsigned long long *candg;
+    unsigned long long *a1g;   // fc1 outputs as {tag, value} granules in the hL layout of `a1` (fused level 2: fc1 in the launch too)
     unsigned *abort_dev;       // set when a candidate wait timed out: later steps stop waiting
     unsigned *abort_host;      // the same, host-mapped: the next call on the handle reports it
-    int fused;                 // candidates live in candg (ar_finalize_kernel)
+    int fused;                 // 0: three launches per sample; 1: fc2 + draw ride in the GRU launch (candidates in candg);
+                               // 2: fc1 rides along as well (its outputs in a1g): ONE launch per sample
     int Hr, Hf, n_cls, upsample;
 };
 
@@ -414,9 +416,57 @@ __device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 
 // fc2 over one 16-class row group + its Gumbel-max candidate per utterance, for local step `ts` (Hf = 256: SW = 4).
 // Used by ar_fc2_kernel (plain candidate arrays) and by the fused launch (granules).  All threads of the workgroup must
 // call it (two barriers); threads >= 256 only take part in those.
+// Bounded wait shared by the in-kernel hand-offs: true once `deadline` has passed (the abort words are then set).
+__device__ __forceinline__ bool handoff_timed_out(const ArModel &m, u64 t0, unsigned spins, int lane) {
+    if ((spins & 255) != 255 || __builtin_amdgcn_s_memrealtime() - t0 <= 25000000ull) return false;      // 0.25 s
+    if (lane == 0) {
+        __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return true;
+}
+
+// fc1 + ReLU over ROWS rows x one utterance tile for local step `ts` (the GRU of that step has written its state).
+// GRAN = 0: outputs to the plain `a1` array (a launch of its own); GRAN = 1: as {tag, value} granules for the fc2 teams of
+// the SAME launch.  `tid` / `worker` as in fc2_body.
+template <int SW, int ROWS, int GRAN>
+__device__ __forceinline__ void fc1_body(const ArModel &m, const ArCall *__restrict__ cp, int ts, int rg, int bt, int nbt,
+                                         float (*red)[16][17], int tid, bool worker) {
+    const int lane = tid & 63, wave = (tid >> 6) & 3;
+    const int wv = worker ? wave : 0;
+    if (!worker) { rg = 0; bt = 0; }
+    const float *h = m.hbuf + (size_t)((ts + 1) & 1) * nbt * m.Hr * 16;
+    float4 wf[SW], hv[SW];
+    load_wfrag<SW>(ROWS == 8 ? m.Wf_fc1h : m.Wf_fc1, rg, 4, wv, (lane & 15) < ROWS ? lane : (lane & 48), wf);
+    load_hfrag<SW>(h, m.Hr, bt, wv, lane, bt == nbt - 1 ? m.live_last : 16, hv);
+    const bool own = ((tid >> 4) & 15) < ROWS;
+    const int row = own ? ROWS * rg + ((tid >> 4) & 15) : 0;
+    const float bias = m.b_fc1[row];
+    __builtin_amdgcn_sched_barrier(0);
+    const ArCall c = *cp;
+    const bool valid = ts >= 0 && c.t_base + ts < c.max_t;
+    const f32x4 acc = mfma_frag<SW>(wf, hv);
+    if (worker) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    }
+    __syncthreads();
+    if (worker && valid && own) {
+        const int rr = (tid >> 4) & 15, bb = tid & 15;
+        float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
+        v += bias;
+        v = v > 0.f ? v : 0.f;
+        const size_t at = hl_index(m.Hf, bt * 16 + bb, row);
+        if (GRAN) ps_store(m.a1g + at, ((u64)(unsigned)(c.t_base + ts + 1) << 32) | __float_as_uint(v));
+        else m.a1[at] = v;
+    }
+}
+
 // `tid` = index inside the 256-thread team that computes (rg, bt); `worker` = false for threads that only keep the
 // workgroup's barriers company (the tail of a 320/384-thread block, teams past the last (rg, bt) of a 1024-thread block).
-template <int GRANULES>
+// A1G = 1: the fc1 outputs come as granules from fc1 teams of the SAME launch (bounded sweep until every tag is this
+// step's); the weights and the draw's noise are in registers by then.
+template <int GRANULES, int A1G>
 __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restrict__ cp, int ts, int rg, int bt, int nbt,
                                          float (*red)[16][17], float (*sc)[17], int tid, bool worker) {
     const int lane = tid & 63, wave = (tid >> 6) & 3;
@@ -424,7 +474,7 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
     if (!worker) { rg = 0; bt = 0; }
     float4 wf[4], hv[4];
     load_wfrag<4>(m.Wf_fc2, rg, 4, wv, lane, wf);
-    load_hfrag<4>(m.a1, m.Hf, bt, wv, lane, bt == nbt - 1 ? m.live_last : 16, hv);
+    if (!A1G) load_hfrag<4>(m.a1, m.Hf, bt, wv, lane, bt == nbt - 1 ? m.live_last : 16, hv);
     const int rr = (tid >> 4) & 15, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;      // bg = decode slot
     const float bias = m.b_fc2[cls];
     __builtin_amdgcn_sched_barrier(0);
@@ -440,6 +490,34 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
     const float g = -logf(-logf(((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f)));
     const bool live = ts >= 0 && t < c.max_t && sl.row >= 0 && lt >= 0 && lt < sl.len;
     __builtin_amdgcn_sched_barrier(0);
+    if (A1G) {
+        // a_t of this tile from the fc1 teams of this launch: the 16 granules behind this lane's four operand words
+        const int live_cols = bt == nbt - 1 ? m.live_last : 16;
+        const int hl = (lane & 15) < live_cols ? lane : (lane & 48);
+        const u64 *gp = m.a1g + (((size_t)bt * (m.Hf >> 2)) * 16 + (size_t)wv * 4 * 64 + hl) * 4;
+        const unsigned tag = (unsigned)(t + 1);
+        const bool need = ts >= 0 && t < c.max_t;                   // fc1 publishes exactly then (wave-uniform)
+        u64 gv[16];
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        bool gave_up = !need || __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        for (unsigned spins = 0; !gave_up; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gv[4 * s + q] = ps_load(gp + (size_t)s * 256 + q);
+                    ok &= (unsigned)(gv[4 * s + q] >> 32) == tag;
+                }
+            if (__all(ok)) break;
+            gave_up = handoff_timed_out(m, t0, spins, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            hv[s] = gave_up ? make_float4(0.f, 0.f, 0.f, 0.f)
+                            : make_float4(__uint_as_float((unsigned)gv[4 * s]), __uint_as_float((unsigned)gv[4 * s + 1]),
+                                          __uint_as_float((unsigned)gv[4 * s + 2]), __uint_as_float((unsigned)gv[4 * s + 3]));
+    }
     const f32x4 acc = mfma_frag<4>(wf, hv);
     if (worker) {
 #pragma unroll
@@ -469,20 +547,28 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
     }
 }
 
+// FUSED = 2: fc1 of step t-1 rides along as well -- the grid is [fc1 teams | fc2 teams | GRU workgroups], fc1 reads the state the
+// previous launch wrote, hands a_{t-1} to the fc2 teams as granules, they hand the candidates to the gate waves: ONE launch per
+// sample, two chained in-kernel hand-offs under the W_hh h MFMA phase.
 template <int SW, int NB, int LEADP, int FUSED>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
 __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt,
-                                                               int n_fc2) {
+                                                               int n_fc1, int n_fc2) {
     __shared__ float red[NB][4][16][17];
     __shared__ __attribute__((aligned(16))) float mt[256];            // mu-law decode table (row group 0 emits the samples)
     __shared__ float sc[16][17];                                       // FUSED: scores of an fc2 workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, Hr = m.Hr;
     int rg = blockIdx.x, pass = blockIdx.y;
     if (FUSED) {
-        if ((int)blockIdx.x < n_fc2) {                                 // fc2 + draw of the PREVIOUS step
-            fc2_body<1>(m, cp, t_local - 1, blockIdx.x & 15, blockIdx.x >> 4, nbt, red[0], sc, tid, tid < 256);
+        if (FUSED == 2 && (int)blockIdx.x < n_fc1) {                   // fc1 of the PREVIOUS step: 8-row groups (<= 4 tiles)
+            fc1_body<SW, 8, 1>(m, cp, t_local - 1, blockIdx.x % (m.Hf / 8), blockIdx.x / (m.Hf / 8), nbt, red[0], tid, tid < 256);
             return;
         }
-        const int gb = blockIdx.x - n_fc2;
+        if ((int)blockIdx.x < n_fc1 + n_fc2) {                         // fc2 + draw of the PREVIOUS step
+            const int fb = blockIdx.x - n_fc1;
+            fc2_body<1, FUSED == 2>(m, cp, t_local - 1, fb & 15, fb >> 4, nbt, red[0], sc, tid, tid < 256);
+            return;
+        }
+        const int gb = blockIdx.x - n_fc1 - n_fc2;
         rg = gb % (Hr >> 2);
         pass = gb / (Hr >> 2);
     }
@@ -691,7 +777,8 @@ __device__ __forceinline__ void big_stage_store(float4 *dst, int t4, int tid, co
 // FUSED = 1: as in ar_gru_kernel, the first n_fc2 blocks of the launch run fc2 + draw of the PREVIOUS step and the
 // cell-update waves pick the candidates up through granules -- after the staging barriers, while the MFMA waves compute.
 template <int SW, int FUSED>
-__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc2) {
+__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc1,
+                                                          int n_fc2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Hr = m.Hr;
     float4 *hs = (float4 *)smem;                                             // [2][Hr*4] float4 = two state tiles
@@ -699,15 +786,22 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int blk = blockIdx.x, passy = blockIdx.y;
     if (FUSED) {
-        if ((int)blockIdx.x < n_fc2) {
-            // four 256-thread teams per workgroup, one (row group, tile) each: 4 nbt fc2 workgroups in front of the GRU ones
-            const int team = tid >> 8, pair = blockIdx.x * 4 + team;
-            char *base = smem + (size_t)team * (5 * 16 * 17 * sizeof(float));
-            fc2_body<1>(m, cp, t_local - 1, pair & 15, pair >> 4, nbt, (float (*)[16][17])base,
-                        (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, pair < 16 * nbt);
+        // four 256-thread teams per workgroup, one (row group, tile) each: 4 nbt fc1 and 4 nbt fc2 workgroups in front of the GRU ones
+        const int team = tid >> 8;
+        char *base = smem + (size_t)team * (5 * 16 * 17 * sizeof(float));
+        if (FUSED == 2 && (int)blockIdx.x < n_fc1) {                   // fc1 of the previous step: 16-row groups
+            const int pair = blockIdx.x * 4 + team;
+            fc1_body<SW, 16, 1>(m, cp, t_local - 1, pair % (m.Hf / 16), pair / (m.Hf / 16), nbt, (float (*)[16][17])base, tid & 255,
+                                pair < (m.Hf / 16) * nbt);
             return;
         }
-        const int gb = blockIdx.x - n_fc2;
+        if ((int)blockIdx.x < n_fc1 + n_fc2) {
+            const int pair = (blockIdx.x - n_fc1) * 4 + team;
+            fc2_body<1, FUSED == 2>(m, cp, t_local - 1, pair & 15, pair >> 4, nbt, (float (*)[16][17])base,
+                                    (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, pair < 16 * nbt);
+            return;
+        }
+        const int gb = blockIdx.x - n_fc1 - n_fc2;
         blk = gb % (Hr >> 4);
         passy = gb / (Hr >> 4);
     }
@@ -876,28 +970,20 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
 template <int SW, int ROWS>
 __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
     __shared__ float red[4][16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = blockIdx.x, bt = blockIdx.y;
-    AR_STAMP(tid == 0, 1, 0);
-    const float *h = m.hbuf + (size_t)((t_local + 1) & 1) * nbt * m.Hr * 16;
-    float4 wf[SW], hv[SW];
-    load_wfrag<SW>(ROWS == 8 ? m.Wf_fc1h : m.Wf_fc1, rg, 4, wave, (lane & 15) < ROWS ? lane : (lane & 48), wf);
-    load_hfrag<SW>(h, m.Hr, bt, wave, lane, bt == nbt - 1 ? m.live_last : 16, hv);
-    const bool own = (tid >> 4) < ROWS;
-    const int row = own ? ROWS * rg + (tid >> 4) : 0;
-    const float bias = m.b_fc1[row];
-    __builtin_amdgcn_sched_barrier(0);
-    const ArCall c = *cp;
-    const bool valid = c.t_base + t_local < c.max_t;
-    const f32x4 acc = mfma_frag<SW>(wf, hv);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-    AR_STAMP(tid == 0, 1, 1);
-    __syncthreads();
-    const int rr = tid >> 4, bb = tid & 15;
-    float v = ((red[0][rr][bb] + red[1][rr][bb]) + red[2][rr][bb]) + red[3][rr][bb];
-    v += bias;
-    if (valid && own) m.a1[hl_index(m.Hf, bt * 16 + bb, row)] = v > 0.f ? v : 0.f;
-    AR_STAMP(tid == 0, 1, 3);
+    AR_STAMP(threadIdx.x == 0, 1, 0);
+    fc1_body<SW, ROWS, 0>(m, cp, t_local, blockIdx.x, blockIdx.y, nbt, red, threadIdx.x, true);
+    AR_STAMP(threadIdx.x == 0, 1, 3);
+}
+
+// Trailing launch of a fully fused replay: fc1 and fc2 + draw of the replay's LAST sample (no GRU step follows inside the
+// replay); fc1 teams first, the fc2 teams wait for them through the granules.  Grid = (Hf / ROWS) * nbt + 16 * nbt blocks.
+template <int SW, int ROWS>
+__global__ __launch_bounds__(256) void ar_fc12_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
+    __shared__ float red[4][16][17];
+    __shared__ float sc[16][17];
+    const int n1 = (m.Hf / ROWS) * nbt;
+    if ((int)blockIdx.x < n1) fc1_body<SW, ROWS, 1>(m, cp, t_local, blockIdx.x % (m.Hf / ROWS), blockIdx.x / (m.Hf / ROWS), nbt, red, threadIdx.x, true);
+    else fc2_body<1, 1>(m, cp, t_local, (blockIdx.x - n1) & 15, (blockIdx.x - n1) >> 4, nbt, red, sc, threadIdx.x, true);
 }
 
 // Philox4x32-10, word `k & 3` of counter (t, utt, k >> 2, 0): the sampling protocol's stream.
@@ -921,7 +1007,7 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     __shared__ float red[4][16][17];
     __shared__ float sc[16][17];
     AR_STAMP(threadIdx.x == 0, 2, 0);
-    fc2_body<GRANULES>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc, threadIdx.x, true);
+    fc2_body<GRANULES, 0>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc, threadIdx.x, true);
     AR_STAMP(threadIdx.x == 0, 2, 3);
 }
 
@@ -1432,9 +1518,9 @@ struct vqcpc_vocoder {
     // step overlaps the other's fc1/fc2; there is no edge between them inside a graph.
     struct Group {
         ArCall *call = nullptr;          // device
-        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur, candg;   // candg: candidate granules + the abort word behind them
+        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur, candg, a1g;   // candg: candidate granules + the abort word behind them
         std::map<int, hipGraphExec_t> graphs;   // key: (tiles in the group, live columns of the last tile, lead6)
-        const void *baked[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
+        const void *baked[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
     } grp[2];
     int two_groups = 1;                  // 0 = always one group
     hipStream_t side_stream = nullptr;
@@ -1445,7 +1531,8 @@ struct vqcpc_vocoder {
     unsigned *abort_host = nullptr;      // its abort flag: pinned host memory the kernel writes and the host reads without a HIP call
     HostStage stage;
     float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
-    int fuse_fc2 = 1;                    // calls of up to 4 tiles: fc2 of step t-1 and the GRU step t share one launch
+    int fuse_fc2 = 1;                    // fc2 + draw of step t-1 and the GRU step t share one launch
+    int fuse_fc1 = 1;                    // ... and fc1 of step t-1 as well: ONE launch per sample (needs fuse_fc2)
     int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
     bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
@@ -1473,7 +1560,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     for (auto &g : v->grp) {
         for (auto &kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
         if (g.call) (void)hipFree(g.call);
-        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur, &g.candg};
+        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur, &g.candg, &g.a1g};
         for (DevBuf *b : gb) b->release();
     }
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
@@ -1616,6 +1703,11 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         v->fuse_fc2 = value != 0;
         return VQCPC_OK;
     }
+    if (!strcmp(name, "fuse_fc1")) {
+        if ((value != 0) != (v->fuse_fc1 != 0)) clear_graphs(v);
+        v->fuse_fc1 = value != 0;
+        return VQCPC_OK;
+    }
     if (!strcmp(name, "persistent")) {
         VQ_REQUIRE(value >= -1 && value <= 1, "persistent must be -1 (auto), 0 or 1");
         v->persistent = value;
@@ -1701,7 +1793,8 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     if (big && !v->big_attr_set) {
         switch (SW) {
 #define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
-                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
+                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
+                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
             default: break;
@@ -1711,20 +1804,27 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     // Fused schedule (m.fused): step i = { fc2 of step i-1  ||  GRU of step i } in ONE launch, then fc1 of step i; the
     // fc2 of the replay's last step runs as a trailing launch (before the slot records change), so the first launch of a
     // replay carries no fc2 blocks.
+    // Level 2 (m.fused == 2): fc1 of step i-1 rides along too -- ONE launch per sample; the trailing launch is fc1 + fc2.
     const int rgs = v->d.Hr / 4, npass = (nbt + 1) / 2;
+    const int f2_full = big ? (v->d.n_cls / 16) * nbt / 4 : (v->d.n_cls / 16) * nbt;
+    const int f1_full = big ? (v->d.Hf / 16) * nbt / 4 : (v->d.Hf / 8) * nbt;       // 16-row groups in teams of 4 / 8-row groups
     for (int i = 0; i < n; ++i) {
-        const int nf = (m.fused && i > 0) ? (big ? (v->d.n_cls / 16) * nbt / 4 : (v->d.n_cls / 16) * nbt) : 0;
+        const int nf = (m.fused && i > 0) ? f2_full : 0;
+        const int n1 = (m.fused == 2 && i > 0) ? f1_full : 0;
         switch (SW) {
 #define CASE(k) case k: \
-            if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, nf); \
-            else if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, nf); \
-            else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, nf); \
-            else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, nf); \
-            else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0); \
-            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0); \
-            else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0); \
-            else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0); \
-            if (tf) break; \
+            if (m.fused == 2 && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 2>), dim3(n1 + nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, n1, nf); \
+            else if (m.fused == 2 && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 2>), dim3(n1 + nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, n1, nf); \
+            else if (m.fused == 2) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 2>), dim3(n1 + nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, n1, nf); \
+            else if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, nf); \
+            else if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
+            else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
+            else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
+            else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
+            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, 0); \
+            else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
+            else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
+            if (tf || m.fused == 2) break; \
             if (nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
             else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
             break;
@@ -1734,7 +1834,18 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
         }
         if (!tf && !m.fused) hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
     }
-    if (!tf && m.fused) hipLaunchKernelGGL(ar_fc2_kernel<1>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, n - 1);
+    if (!tf && m.fused == 1) hipLaunchKernelGGL(ar_fc2_kernel<1>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, n - 1);
+    if (!tf && m.fused == 2) {
+        switch (SW) {
+#define CASE(k) case k: \
+            if (nbt <= 4) hipLaunchKernelGGL((ar_fc12_kernel<k, 8>), dim3((v->d.Hf / 8 + v->d.n_cls / 16) * nbt), blk, 0, s, m, (const ArCall *)call, n - 1, nbt); \
+            else hipLaunchKernelGGL((ar_fc12_kernel<k, 16>), dim3((v->d.Hf / 16 + v->d.n_cls / 16) * nbt), blk, 0, s, m, (const ArCall *)call, n - 1, nbt); \
+            break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+#undef CASE
+            default: break;
+        }
+    }
     if (!tf) hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, call, n);
     hipLaunchKernelGGL(ar_next_row_kernel, dim3(nbt * 16), dim3(256), 0, s, m, (const ArCall *)call);
@@ -1892,6 +2003,9 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         const size_t cg_bytes = (size_t)nb * 16 * 16 * sizeof(u64);          // granules, then one 64-byte block for the abort word
         TRY(G.candg.reserve(cg_bytes + 64));
         HIP_TRY(hipMemsetAsync(G.candg.p, 0, cg_bytes + 64, s));
+        const size_t a1g_bytes = (size_t)nb * d.Hf * 16 * sizeof(u64);       // fc1 outputs as granules (fused level 2)
+        TRY(G.a1g.reserve(a1g_bytes));
+        HIP_TRY(hipMemsetAsync(G.a1g.p, 0, a1g_bytes, s));
         ArCall &c = calls[g];
         c = ArCall{};
         c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
@@ -1917,13 +2031,14 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         }
         m.lead6 = n_grp == 2 && nb <= 2;
         m.candg = G.candg.as<u64>();
+        m.a1g = G.a1g.as<u64>();
         m.abort_dev = (unsigned *)((char *)G.candg.p + cg_bytes);
         m.abort_host = abort_dev_ptr;
         {
             const size_t big_lds = (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
             const bool big = v->big_min_tiles > 0 && nb >= v->big_min_tiles && Hr % 16 == 0 && big_lds <= 160 * 1024;
             (void)big;
-            m.fused = v->fuse_fc2 && !tf && gmax[g] < (1 << 24);
+            m.fused = (v->fuse_fc2 && !tf && gmax[g] < (1 << 24)) ? (v->fuse_fc1 ? 2 : 1) : 0;
         }
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
@@ -1936,13 +2051,13 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         for (int g = 0; g < n_grp; ++g) {
             auto &G = v->grp[g];
             // a graph bakes its ArModel (buffer pointers): drop cached graphs if a workspace moved
-            const void *now[7] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p, G.candg.p};
+            const void *now[8] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p, G.candg.p, G.a1g.p};
             if (memcmp(G.baked, now, sizeof now) != 0) {
                 for (auto &kv : G.graphs) (void)hipGraphExecDestroy(kv.second);
                 G.graphs.clear();
                 memcpy(G.baked, now, sizeof now);
             }
-            const int gkey = (((tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6) * 2 + (tf ? 1 : 0)) * 2 + models[g].fused;   // what the capture bakes
+            const int gkey = (((tiles[g] * 17 + models[g].live_last) * 2 + models[g].lead6) * 2 + (tf ? 1 : 0)) * 3 + models[g].fused;   // what the capture bakes
             auto it = G.graphs.find(gkey);
             if (it == G.graphs.end()) {
                 hipGraph_t gr = nullptr;
@@ -2029,6 +2144,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
     const int nf = tbig ? (v->d.n_cls / 16) * c.nbt / 4 : (v->d.n_cls / 16) * c.nbt;   // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
+    const int n1 = m.fused == 2 ? (tbig ? (v->d.Hf / 16) * c.nbt / 4 : (v->d.Hf / 8) * c.nbt) : 0;   // ... and fc1 blocks in front of those
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
             if (pass == 1) HIP_TRY(hipEventRecord(v->ev0, s));
@@ -2037,14 +2153,17 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                 if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0 && m.fused && !tbig && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
-                    else if (which == 0 && m.fused && !tbig && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
-                    else if (which == 0 && m.fused && !tbig) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, nf); \
-                    else if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
-                    else if (which == 0 && tbig && m.fused) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 1, c.nbt, nf); \
-                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt, 0); \
-                    else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
-                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0); \
+                    if (which == 0 && m.fused == 2 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 2>), dim3(n1 + nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 1, c.nbt, n1, nf); \
+                    else if (which == 0 && m.fused == 2 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 2>), dim3(n1 + nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 1, c.nbt, n1, nf); \
+                    else if (which == 0 && m.fused == 2) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 2>), dim3(n1 + nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, n1, nf); \
+                    else if (which == 0 && m.fused && !tbig && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 1, c.nbt, 0, nf); \
+                    else if (which == 0 && m.fused && !tbig && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, 0, nf); \
+                    else if (which == 0 && m.fused && !tbig) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, 1, c.nbt, 0, nf); \
+                    else if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
+                    else if (which == 0 && tbig && m.fused) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 1, c.nbt, 0, nf); \
+                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
+                    else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
+                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
                     else if (c.nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
                     break;
@@ -2061,7 +2180,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
         out_us[which] = ms * 1e3f / (float)reps;
     }
     out_us[3] = (float)(c.nbt * 16);       // decode slots one launch of the timed configuration covers
-    out_us[4] = m.fused ? (tbig ? 5.f : 4.f) : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
+    out_us[4] = m.fused == 2 ? (tbig ? 7.f : 6.f) : m.fused ? (tbig ? 5.f : 4.f) : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
     return VQCPC_OK;
 }
 
