@@ -200,8 +200,9 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * and the GRU step of sample t share ONE launch -- W_hh h does not depend on the drawn sample, so it runs while the fc2
  * workgroups of the same launch produce the candidates, which the GRU's gate waves then pick up through 8-byte granules.
  * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) aborts like `persistent`.
- * fuse_fc1 (default 1, needs fuse_fc2): fc1 of sample t-1 rides in the same launch as well -- it reads the state the
- * previous launch wrote and hands its outputs to the fc2 teams as granules: ONE launch per sample.
+ * fuse_fc1 (default 0, needs fuse_fc2): fc1 of sample t-1 rides in the same launch as well -- it reads the state the
+ * previous launch wrote and hands its outputs to the fc2 teams as granules: ONE launch per sample.  Same bits, but
+ * measured slower than two launches at every batch size (the hand-off is 32 KB per fc2 team), so it is off.
  * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
  * use_graph: replay the per-sample kernels from a captured hipGraph
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).

@@ -1532,7 +1532,9 @@ struct vqcpc_vocoder {
     HostStage stage;
     float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
     int fuse_fc2 = 1;                    // fc2 + draw of step t-1 and the GRU step t share one launch
-    int fuse_fc1 = 1;                    // ... and fc1 of step t-1 as well: ONE launch per sample (needs fuse_fc2)
+    int fuse_fc1 = 0;                    // ... and fc1 of step t-1 as well: ONE launch per sample (needs fuse_fc2).  Measured and left
+                                         // off: the a_t hand-off is 32 KB of granules per fc2 team and the fc1 teams take CUs from the GRU
+                                         // workgroups -- 9.9 vs 9.6 us per step at 32 utterances, 19.0 vs 15.5 at 128 (r02_gru_variants.csv)
     int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
     bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
