@@ -9,7 +9,10 @@
 // fragment from L2 (fragment-ordered, 16 B per lane), multiplies it with the whole state
 // matrix h (K x 16-utterance tiles) on v_mfma_f32_16x16x4_f32, reduces the 4 K-quarters
 // through LDS and applies the cell update.  The all-gather of h between steps is the kernel
-// boundary; the per-sample kernels are replayed from a hipGraph.
+// boundary; the per-sample kernels are replayed from a hipGraph.  Two launches per sample: fc1, then ONE launch that
+// carries fc2 + draw of the previous sample in front of the GRU step (W_hh h does not depend on the drawn sample; the
+// candidates reach the GRU's gate waves through in-kernel granules).  A call on a single utterance runs on the
+// persistent decoder instead (ar_persist_kernel: resident workgroups, weights in registers, no launches per sample).
 #include "common.h"
 #include <math.h>
 #include <stdio.h>
