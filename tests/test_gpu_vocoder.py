@@ -203,6 +203,40 @@ def test_tile_groups_and_large_batch_kernel_are_bit_identical():
         assert torch.equal(m, ref), name
 
 
+def test_large_batch_kernel_many_tiles_per_workgroup_bit_identical():
+    """The large-batch kernel walks several tiles per workgroup (weights stay in registers, state tiles go through a
+    double buffer in LDS).  200 ragged utterances = 13 tiles, the last one partly filled: ONE group (4 tile groups of
+    4 / 3 / 3 / 3 tiles, fc2 teams walking two tiles each), the default (two groups of 7 and 6 tiles), both also without
+    the fused fc2 launch, all against the small kernel (oracle-checked above) -- the same bits."""
+    voc, _ = vocoder()
+    B = 200
+    z = synth.randint("mt/z", (B, 3), 512).cuda()
+    spk = (torch.arange(B) * 3 % 102).cuda()
+    n_codes = [1 + (i % 3) for i in range(B)]
+    ids = list(range(5000, 5000 + B))
+    outs = {}
+    try:
+        for name, opts in (("small_kernel", {"two_groups": 0, "big_min_tiles": 0}),
+                           ("big_one_group", {"two_groups": 0, "big_min_tiles": 5}),
+                           ("big_two_groups", {"two_groups": 1, "big_min_tiles": 5}),
+                           ("big_one_group_three_launches", {"two_groups": 0, "big_min_tiles": 5, "fuse_fc2": 0}),
+                           ("big_one_group_150_slots", {"two_groups": 0, "big_min_tiles": 5, "slots": 150})):
+            for k, val in opts.items():
+                voc.set_option(k, val)
+            outs[name] = voc.generate(z, spk, n_codes=n_codes, seed=17, utt_ids=ids, return_mulaw=True)[1]
+            voc.set_option("slots", 0)
+            voc.set_option("fuse_fc2", 1)
+    finally:
+        voc.set_option("two_groups", 1)
+        voc.set_option("big_min_tiles", 5)
+        voc.set_option("slots", 0)
+        voc.set_option("fuse_fc2", 1)
+    ref = outs["small_kernel"]
+    assert int((ref != 0).sum()) > 50000
+    for name, m in outs.items():
+        assert torch.equal(m, ref), name
+
+
 def test_default_paths_at_many_batch_sizes_equal_single_utterance_calls():
     """Default options at batch sizes that take different code paths -- one tile with dead columns (5), two
     groups (40: a 2-tile and a 1-tile group), the large-batch kernel with a partly filled last tile (100),

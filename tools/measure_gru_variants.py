@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GRU-step kernel variants at a given batch: the packed 12-row two-tile kernel (224 workgroups)
-against the full-16-row-tile LDS-staged kernel (56 workgroups per tile pair), HIP events around 2000 back-to-back
+against the full-16-row-tile LDS-staged kernel (56 workgroups per tile pair), HIP events around 1000 back-to-back
 launches each (includes the ~1.5 us dependent-launch boundary), plus the whole decode step per sample.
 
     python3 tools/measure_gru_variants.py [utterances ...]      (default 16 32 48 64 96)
@@ -31,7 +31,7 @@ for B in sizes:
         voc.generate(z, spk, seed=1, utt_base=0)
         voc.generate(z, spk, seed=1, utt_base=0)
         ms, n = voc.last_timing()
-        kt = voc.kernel_times(2000)
+        kt = voc.kernel_times(1000)
         print(f"{B},{name},{kt[0]:.3f},{kt[1]:.3f},{kt[2]:.3f},{int(kt[3])},{int(kt[4])},{ms * 1e3 / n:.3f}", flush=True)
         voc.set_option("big_min_tiles", 5)
         voc.set_option("two_groups", 1)
