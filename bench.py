@@ -282,10 +282,16 @@ def run_manifest(enc, voc, dev, n_utt, max_batch):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     samples = sum(int(w.numel()) for w in wavs)
+    loop_ms, steps = voc.last_timing()                          # the decode loop alone (HIP events inside generate)
+    max_batch = driver.fit_slots([int(w.numel()) for w in wavs], max_batch)       # what convert_utterances used
     return {"workload": f"synthetic manifest (configs[4] stand-in): {n_utt} utterances, log-normal 1-10 s, "
-                        f"encoder in length buckets, decode by continuous batching over {max_batch} slots",
+                        f"encoder in length buckets, decode by continuous batching over {max_batch} slots "
+                        f"(total / longest utterance, in whole tiles)",
+            "slots": max_batch,
             "utterances": n_utt, "audio_seconds": samples / 16000.0, "wall_s": dt,
-            "samples_per_s": samples / dt, "realtime_factor_16k": samples / 16000.0 / dt}
+            "samples_per_s": samples / dt, "realtime_factor_16k": samples / 16000.0 / dt,
+            "decode_loop_s": loop_ms * 1e-3, "decode_steps": int(steps), "us_per_step": loop_ms * 1e3 / max(steps, 1),
+            "slot_occupancy": samples / float(max(steps, 1) * max_batch)}
 
 
 def gru_roofline(voc, n_utt, step_us):

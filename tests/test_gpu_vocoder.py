@@ -203,11 +203,11 @@ def test_tile_groups_and_large_batch_kernel_are_bit_identical():
         assert torch.equal(m, ref), name
 
 
-def test_large_batch_kernel_many_tiles_per_workgroup_bit_identical():
-    """The large-batch kernel walks several tiles per workgroup (weights stay in registers, state tiles go through a
-    double buffer in LDS).  200 ragged utterances = 13 tiles, the last one partly filled: ONE group (4 tile groups of
-    4 / 3 / 3 / 3 tiles, fc2 teams walking two tiles each), the default (two groups of 7 and 6 tiles), both also without
-    the fused fc2 launch, all against the small kernel (oracle-checked above) -- the same bits."""
+def test_large_batch_kernel_13_tiles_one_group_and_two_groups_bit_identical():
+    """200 ragged utterances = 13 tiles, the last one partly filled, on the large-batch kernel: ONE group (7 passes of
+    two tiles, the last pass with a single tile), the default (two groups of 7 and 6 tiles on two streams), one group
+    without the fused fc2 launch and with continuous batching over 150 slots, all against the small kernel
+    (oracle-checked above) -- the same bits."""
     voc, _ = vocoder()
     B = 200
     z = synth.randint("mt/z", (B, 3), 512).cuda()

@@ -313,17 +313,8 @@ __device__ unsigned long long g_ar_stamps[160 * 3 * 6];
 extern "C" int vqcpc_debug_ar_stamps(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ar_stamps), sizeof(g_ar_stamps)) == hipSuccess ? 0 : -1;
 }
-// large-batch kernel: workgroup 1 of the GRU part, local step 100: [tile][k] -- k 0..3 MFMA wave 4 (tile start, MFMAs done,
-// next tile stored, barrier passed), 4..7 cell wave 0 (tile start, candidates resolved, barrier passed, update stored)
-__device__ unsigned long long g_big_stamps[32 * 8];
-#define BIG_STAMP(cond, tile, k) do { if ((cond) && gb == 1 && t_local == 100 && (tile) < 32) \
-        g_big_stamps[(tile) * 8 + (k)] = wall_clock64(); } while (0)
-extern "C" int vqcpc_debug_big_stamps(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamps), sizeof(g_big_stamps)) == hipSuccess ? 0 : -1;
-}
 #else
 #define AR_STAMP(cond, kern, i) do { } while (0)
-#define BIG_STAMP(cond, tile, k) do { } while (0)
 #endif
 
 struct ArModel {               // constant per handle (baked into the captured graph)
@@ -760,232 +751,204 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
     }
 }
 
-// Large-batch GRU step (>= big_min_tiles utterance tiles in flight).  The wave-specialised kernel above re-reads
+// Large-batch GRU step (>= 8 utterance tiles in flight).  The wave-specialised kernel above re-reads
 // the state tile once per row group; at many tiles the per-CU L2 read rate (~65 GB/s) is the limit
 // (DESIGN "what bounds K7a"), and behind it the MFMA pipe: 16 waves x 112 MFMAs = 6.8 us per SIMD when every
-// 16-row MFMA tile carries 4 padding rows.  Here one 1024-thread workgroup owns 16 hidden units and EVERY G-th tile
-// (G = tile groups = gridDim / (Hr/16): the launcher keeps (Hr/16) G + the fc2 workgroups within the 256 CUs):
-//  * the 48 gate rows are three FULL 16-row tiles (r, z, n of the 16 units: fragment layout Wf_hh16), held in the
-//    registers of 12 MFMA waves (gate x K quarter) for the whole launch -- 172 KB of weights per workgroup, ONCE;
-//  * state tiles (57 KB) go through a double buffer in LDS: while the MFMA waves multiply tile i they have tile i+1
-//    in flight, and the 4 oldest waves (one hidden unit per lane) chase the cell update's operand chain one tile
-//    ahead and, after the barrier that ends tile i, update it from the K-quarter partials;
-//  * one barrier per tile.  The MFMA pipe sees 56 MFMAs per wave and tile back to back.
+// 16-row MFMA tile carries 4 padding rows.  Here one 1024-thread workgroup owns 16 hidden units and TWO tiles:
+//  * the two state tiles (2 x 57 KB) are staged ONCE in LDS and shared by all MFMA waves;
+//  * the 48 gate rows are three FULL 16-row tiles (r, z, n of the 16 units: fragment layout Wf_hh16), so 12
+//    waves (gate x K quarter) do the MFMAs -- 25 % fewer MFMAs and weight bytes (172 KB) than padded 12-row groups;
+//  * the 4 oldest waves do nothing but the cell update's operand chain and the update itself (2 units per lane).
 // Per-row arithmetic is unchanged (same K quarters, same accumulator pairs): bit-identical to ar_gru_kernel.
-// staging of one state tile by the 768 threads of the MFMA waves (`mt` = thread index among them): request / store halves
-__device__ __forceinline__ void big_stage_load(const float4 *src, int t4, int mt, bool on, float4 (&st)[5]) {
+// Grid = (Hr/16, ceil(nbt/2)).
+// staging of one state tile by all 1024 threads: request / store halves (the barrier is the caller's)
+__device__ __forceinline__ void big_stage_load(const float4 *src, int t4, int tid, bool on, float4 (&st)[4]) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int i = mt + 768 * j;
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
         st[j] = (on && i < t4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-__device__ __forceinline__ void big_stage_store(float4 *dst, int t4, int mt, bool on, const float4 (&st)[5]) {
+__device__ __forceinline__ void big_stage_store(float4 *dst, int t4, int tid, const float4 (&st)[4]) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int i = mt + 768 * j;
-        if (on && i < t4) dst[i] = st[j];
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 1024 * j;
+        if (i < t4) dst[i] = st[j];
     }
 }
 
-// FUSED = 1: as in ar_gru_kernel, the first n_fc2 blocks of the launch run fc2 + draw of the PREVIOUS step -- four
-// 256-thread teams per workgroup, a team = one 16-class row group and every (n_fc2/4)-th tile -- and the cell-update waves
-// pick the candidates up through granules while the MFMA waves compute.
+// FUSED = 1: as in ar_gru_kernel, the first n_fc2 blocks of the launch run fc2 + draw of the PREVIOUS step and the
+// cell-update waves pick the candidates up through granules -- after the staging barriers, while the MFMA waves compute.
 template <int SW, int FUSED>
-__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc2,
-                                                          int G) {
+__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc1,
+                                                          int n_fc2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Hr = m.Hr;
     float4 *hs = (float4 *)smem;                                             // [2][Hr*4] float4 = two state tiles
-    float (*red)[3][4][16][17] = (float (*)[3][4][16][17])(smem + (size_t)2 * Hr * 16 * sizeof(float));   // [buffer][gate][kq][unit][slot]
+    float (*red)[3][4][16][17] = (float (*)[3][4][16][17])(smem + (size_t)2 * Hr * 16 * sizeof(float));   // [tile][gate][kq][unit][slot]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int gb = blockIdx.x;
+    int blk = blockIdx.x, passy = blockIdx.y;
     if (FUSED) {
-        if ((int)blockIdx.x < n_fc2) {
-            const int team = tid >> 8, id = blockIdx.x * 4 + team, nc = n_fc2 >> 2;      // the 4 teams of a workgroup share a tile chunk
-            char *base = smem + (size_t)team * (5 * 16 * 17 * sizeof(float));
-            for (int bt = id >> 4; bt < nbt; bt += nc)
-                fc2_body<1, 0>(m, cp, t_local - 1, id & 15, bt, nbt, (float (*)[16][17])base,
-                               (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, true);
+        // four 256-thread teams per workgroup, one (row group, tile) each: 4 nbt fc1 and 4 nbt fc2 workgroups in front of the GRU ones
+        const int team = tid >> 8;
+        char *base = smem + (size_t)team * (5 * 16 * 17 * sizeof(float));
+        if (FUSED == 2 && (int)blockIdx.x < n_fc1) {                   // fc1 of the previous step: 16-row groups
+            const int pair = blockIdx.x * 4 + team;
+            fc1_body<SW, 16, 1>(m, cp, t_local - 1, pair % (m.Hf / 16), pair / (m.Hf / 16), nbt, (float (*)[16][17])base, tid & 255,
+                                pair < (m.Hf / 16) * nbt);
             return;
         }
-        gb -= n_fc2;
+        if ((int)blockIdx.x < n_fc1 + n_fc2) {
+            const int pair = (blockIdx.x - n_fc1) * 4 + team;
+            fc2_body<1, FUSED == 2>(m, cp, t_local - 1, pair & 15, pair >> 4, nbt, (float (*)[16][17])base,
+                                    (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, pair < 16 * nbt);
+            return;
+        }
+        const int gb = blockIdx.x - n_fc1 - n_fc2;
+        blk = gb % (Hr >> 4);
+        passy = gb / (Hr >> 4);
     }
-    const int blk = gb % (Hr >> 4), g0 = gb / (Hr >> 4);
-    const int nt = (nbt - g0 + G - 1) / G;                                   // tiles g0, g0 + G, ...: at least one (G <= nbt)
+    const int bt0 = passy * 2, nb = nbt - bt0 < 2 ? nbt - bt0 : 2;
     const size_t hsz = (size_t)nbt * Hr * 16;
     const float *hin = m.hbuf + (size_t)(t_local & 1) * hsz;
     float *hout = m.hbuf + (size_t)((t_local + 1) & 1) * hsz;
     const int t4 = Hr * 4;                                                   // float4 per state tile
-    const float4 *src = (const float4 *)hin;
+    const float4 *src = (const float4 *)hin + (size_t)bt0 * t4;
+    float4 st[4];
 
-    // The two roles are separate code paths (their registers never coexist); both pass the same 1 + nt barriers.
+    // The two roles are separate code paths (their registers never coexist); both pass the same three barriers.
     if (wave < 4) {
-        // ---- cell-update waves: unit 16 blk + 4 wave + u, slot b of the tile in flight.
-        // The operand chain of a tile (slot record + candidates -> x -> Gemb row) is two dependent memory round trips of
-        // 2 - 3 us each under load, twice what the MFMA waves need for a tile (tools/big_timeline.py), and a wave's loads
-        // retire in order.  So these waves stage nothing and run the chain as a pipeline over tiles, every wait being for a
-        // load requested two tiles earlier: after the barrier that ends tile i they update tile i (its Gemb row was
-        // requested at iteration i-2), resolve tile i+2 (candidates -> x -> request of its Gemb row; slot record and
-        // candidates requested at iteration i-2) and request the fixed-address operands of tile i+4.
-        // Candidates: a lane asks for ONE of its slot's 16 granules (row group 4 wave + u) -- all 16 per lane made every
-        // workgroup of the chip poll the same few lines, the slowest loads of the launch -- and the 4 x 4 partial winners
-        // are merged through DPP-free shuffles and a 1 KB LDS exchange among the four waves (first maximum in class order,
-        // as merge_candidates16).  Only tiles 0 and 1 wait for the fc2 workgroups of this launch, while the MFMA waves are
-        // already on the next tile.
-        const int u = lane >> 4, b = lane & 15, ul = 4 * wave + u, unit = 16 * blk + ul, rgq = 4 * blk + wave;
-        u64 *part = (u64 *)(smem + (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float));   // [2][4 waves][16 slots]
-        if (u < 2) __hip_atomic_store(part + (u * 4 + wave) * 16 + b, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ---- cell-update waves: tile q, units 16 blk + 8 uh + 4 p + u (p = 0, 1), slot b
+        const int q = wave & 1, uh = wave >> 1, u = lane >> 4, b = lane & 15;
+        const int gbt = bt0 + q;
+        const int sg = (gbt < nbt ? gbt : nbt - 1) * 16 + b;
+        float ge[2][3] = {}, gc[2][3], bh[2][3], hold[2] = {0.f, 0.f}, hprev[2];
+        size_t hi[2];
+        float *hallp = nullptr;
+        // first level of the operand chain: everything with a fixed address (as in ar_gru_kernel)
+        Cand16 cd;
+        if (!FUSED) load_candidates16(m, sg, cd);
+        const ArSlot sl = m.cur[sg];
         const ArCall c = *cp;
-        const float4 bq = m.bh4[rgq * 4 + u];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int unit = 16 * blk + 8 * uh + 4 * p + u, rgq = 4 * blk + 2 * uh + p;
+            const float4 bq = m.bh4[rgq * 4 + u];
+            const float4 gq = m.gcur4[((size_t)rgq * (nbt * 16) + sg) * 4 + u];
+            bh[p][0] = bq.x; bh[p][1] = bq.y; bh[p][2] = bq.z;
+            gc[p][0] = gq.x; gc[p][1] = gq.y; gc[p][2] = gq.z;
+            hi[p] = hl_index(Hr, sg, unit);
+            hprev[p] = hin[hi[p]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        big_stage_load(src, t4, tid, true, st);
+        __builtin_amdgcn_sched_barrier(0);
+        // second level: x picks the Gemb rows
         const int t = c.t_base + t_local;
-        const unsigned tag = (unsigned)t & 0xFFFFFFu;
-        bool gave_up = false;
-        if (FUSED) gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        struct BigL { ArSlot sl; float4 gq; unsigned lo, hi; };      // requested: slot record, Gcond quad, this lane's candidate
-        struct BigR { float4 eq; float gc0, gc1, gc2; float *hallp; bool active, first; };   // resolved, Gemb row in flight
-        auto request = [&](int i) -> BigL {
-            const int bt = g0 + (i < nt ? i : nt - 1) * G, sg = bt * 16 + b;      // past the end: the last tile again (unused)
-            BigL L;
-            L.sl = m.cur[sg];
-            L.gq = m.gcur4[((size_t)rgq * (nbt * 16) + sg) * 4 + u];
-            if (FUSED) {
-                const u64 g = ps_load(m.candg + ((size_t)bt * 16 + ul) * 16 + b);
-                L.lo = (unsigned)g; L.hi = (unsigned)(g >> 32);
-            } else {
-                L.lo = __float_as_uint(m.cand_s[(size_t)sg * 16 + ul]);
-                L.hi = (unsigned)m.cand_k[(size_t)sg * 16 + ul];
-            }
-            return L;
-        };
-        auto resolve = [&](BigL &L, int i) -> BigR {
-            const int bt = g0 + i * G;
-            const ArSlot sl = L.sl;
-            const int lt = t - sl.t0;
-            BigR R;
-            R.active = t < c.max_t && sl.row >= 0 && lt < sl.len;
-            R.first = lt == 0;
-            if (FUSED) {
-                // this slot's candidate of row group `ul` (step t-1's draw, tag t) from the fc2 workgroups of THIS launch:
-                // asked for again only while its tag is not this step's yet
-                const bool need = R.active && !R.first;
-                const u64 *cg = m.candg + ((size_t)bt * 16 + ul) * 16 + b;
-                const u64 t0 = __builtin_amdgcn_s_memrealtime();
-                for (unsigned spins = 0; !gave_up; ++spins) {
-                    if (__all((L.hi >> 8) == tag || !need)) break;
-                    const u64 g = ps_load(cg);
-                    L.lo = (unsigned)g; L.hi = (unsigned)(g >> 32);
-                    gave_up = handoff_timed_out(m, t0, spins, lane);
-                }
-            }
-            float sc = (FUSED && gave_up) ? -INFINITY : __uint_as_float(L.lo);
-            int cls = FUSED ? (int)(L.hi & 255u) : (int)L.hi;
-            // first maximum over this wave's four row groups (lanes b, b+16, b+32, b+48 in class order) ...
-            {
-                const float s1 = __shfl_down(sc, 16); const int c1 = __shfl_down(cls, 16);
-                if (s1 > sc) { sc = s1; cls = c1; }
-                const float s2 = __shfl_down(sc, 32); const int c2 = __shfl_down(cls, 32);
-                if (s2 > sc) { sc = s2; cls = c2; }
-            }
-            // ... then over the four waves, through LDS: {exchange number, class, score} granules, two buffers
-            u64 *pb = part + (size_t)(i & 1) * 64;
-            const unsigned seq = (unsigned)i + 1u;
-            if (u == 0) __hip_atomic_store(pb + wave * 16 + b, ((u64)((seq << 8) | (unsigned)cls) << 32) | __float_as_uint(sc),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            u64 pv[4];
-            for (;;) {
+        const int lt = t - sl.t0;
+        const bool active = gbt < nbt && t < c.max_t && sl.row >= 0 && lt < sl.len;
+        const bool first = lt == 0;
+        int xf = 0;
+        if (FUSED) {                                             // this wave's share of the staging first: the MFMA waves
+            big_stage_store(hs, t4, tid, st);                    // must not wait behind the candidate hand-off
+            __syncthreads();
+            big_stage_load(src + t4, t4, tid, nb > 1, st);
+            big_stage_store(hs + t4, t4, tid, st);
+            __syncthreads();
+            const bool need = active && !first;
+            const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
+            const unsigned tag = (unsigned)t & 0xFFFFFFu;
+            u64 gv[16];
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            bool gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            for (unsigned spins = 0; !gave_up; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    pv[w] = __hip_atomic_load(pb + w * 16 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ok &= (unsigned)(pv[w] >> 40) == seq;
+                for (int qq = 0; qq < 16; ++qq) {
+                    gv[qq] = ps_load(cg + qq * 16);
+                    ok &= (unsigned)(gv[qq] >> 40) == tag;
                 }
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
+                if (__all(ok || !need)) break;
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {      // 0.25 s
+                    if (lane == 0) {
+                        __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    gave_up = true;
+                }
             }
             float best = -INFINITY;
-            int x = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float sq = __uint_as_float((unsigned)pv[w]);
-                if (sq > best) { best = sq; x = (int)((pv[w] >> 32) & 255u); }
+            for (int qq = 0; qq < 16; ++qq) {
+                const float sq = __uint_as_float((unsigned)gv[qq]);
+                if (!gave_up && sq > best) { best = sq; xf = (int)((gv[qq] >> 32) & 255u); }
             }
-            R.gc0 = L.gq.x; R.gc1 = L.gq.y; R.gc2 = L.gq.z;
-            R.eq = make_float4(0.f, 0.f, 0.f, 0.f);
-            R.hallp = nullptr;
-            if (R.active) {
-                if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
-                else if (R.first) x = m.n_cls / 2;
-                else if (blk == 0 && ul == 0) {                      // emit sample lt-1 (network_vocoder.py:78 output)
+        }
+        if (active) {
+            int x;
+            if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
+            else if (first) x = m.n_cls / 2;
+            else {
+                x = FUSED ? xf : merge_candidates16(cd);
+                if (blk == 0 && uh == 0 && u == 0) {             // emit sample lt-1 (network_vocoder.py:78 output)
                     if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
                     if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
                 }
-                x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
-                R.eq = m.Gemb4[((size_t)x * (Hr >> 2) + rgq) * 4 + u];
+            }
+            x = x < 0 ? 0 : (x >= m.n_cls ? m.n_cls - 1 : x);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int unit = 16 * blk + 8 * uh + 4 * p + u, rgq = 4 * blk + 2 * uh + p;
+                const float4 eq = m.Gemb4[((size_t)x * (Hr >> 2) + rgq) * 4 + u];
+                ge[p][0] = eq.x; ge[p][1] = eq.y; ge[p][2] = eq.z;
                 if (!m.gc_replay) {
                     const float *pg = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
-                    R.gc0 = pg[0]; R.gc1 = pg[Hr]; R.gc2 = pg[2 * Hr];
+                    gc[p][0] = pg[0]; gc[p][1] = pg[Hr]; gc[p][2] = pg[2 * Hr];
                 }
-                if (c.hall) R.hallp = c.hall + ((size_t)sl.row * c.CH + (lt - c.hall_t0)) * Hr + unit;
+                hold[p] = first ? 0.f : hprev[p];
             }
-            return R;
-        };
-        // Two tiles in flight per stage: even tiles live in (Ra, La), odd ones in (Rb, Lb) -- the loop is unrolled by two so
-        // that nothing in flight is ever copied (a register move would wait for its load).
-        BigL La = request(0), Lb = request(1), Lc = request(2), Ld = request(3);
-        BigR Ra, Rb;
-        Ra.active = Rb.active = false;
-        auto step = [&](int i, BigR &R, BigL &L) {
-            const int bt = g0 + i * G;
-            BIG_STAMP(tid == 0, i, 4);
-            const size_t hi = hl_index(Hr, bt * 16 + b, unit);
-            const float hprev = ((const float *)(hs + (size_t)(i & 1) * t4))[hi - (size_t)bt * Hr * 16];
-            __syncthreads();                                         // tile i's partials are in red[i & 1], tile i+1 is staged
-            BIG_STAMP(tid == 0, i, 5);
-            if (i == 0) {                                            // exposed once: waits for the fc2 workgroups
-                Ra = resolve(La, 0);
-                if (nt > 1) Rb = resolve(Lb, 1);
-                La = Lc; Lb = Ld;                                    // tiles 2 and 3: requested with tiles 0 and 1, long here
-            }
-            BIG_STAMP(tid == 0, i, 6);
-            if (R.active) {
-                const float (*rd)[4][16][17] = red[i & 1];
-                const bool first = R.first;
-                const float gr = first ? 0.f : ((rd[0][0][ul][b] + rd[0][1][ul][b]) + rd[0][2][ul][b]) + rd[0][3][ul][b];
-                const float gz = first ? 0.f : ((rd[1][0][ul][b] + rd[1][1][ul][b]) + rd[1][2][ul][b]) + rd[1][3][ul][b];
-                const float gn = first ? 0.f : ((rd[2][0][ul][b] + rd[2][1][ul][b]) + rd[2][2][ul][b]) + rd[2][3][ul][b];
-                const float rr = sigmoidf_((R.eq.x + R.gc0) + (gr + bq.x));
-                const float z = sigmoidf_((R.eq.y + R.gc1) + (gz + bq.y));
-                const float n = tanhf((R.eq.z + R.gc2) + rr * (gn + bq.z));
-                const float hn = (1.0f - z) * n + z * (first ? 0.f : hprev);
-                hout[hi] = hn;
-                if (R.hallp) *R.hallp = hn;
-            }
-            BIG_STAMP(tid == 0, i, 7);
-            if (i + 2 < nt) R = resolve(L, i + 2);
-            if (i + 4 < nt) L = request(i + 4);
-        };
+            if (c.hall) hallp = c.hall + ((size_t)sl.row * c.CH + (lt - c.hall_t0)) * Hr + 16 * blk + 8 * uh + u;
+        }
+        if (!FUSED) {
+            big_stage_store(hs, t4, tid, st);
+            __syncthreads();
+            big_stage_load(src + t4, t4, tid, nb > 1, st);
+            big_stage_store(hs + t4, t4, tid, st);
+            __syncthreads();
+        }
         __syncthreads();
-        for (int i = 0; i < nt; i += 2) {
-            step(i, Ra, La);
-            if (i + 1 < nt) step(i + 1, Rb, Lb);
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ul = 8 * uh + 4 * p + u;
+                const float gr = first ? 0.f : ((red[q][0][0][ul][b] + red[q][0][1][ul][b]) + red[q][0][2][ul][b]) + red[q][0][3][ul][b];
+                const float gz = first ? 0.f : ((red[q][1][0][ul][b] + red[q][1][1][ul][b]) + red[q][1][2][ul][b]) + red[q][1][3][ul][b];
+                const float gn = first ? 0.f : ((red[q][2][0][ul][b] + red[q][2][1][ul][b]) + red[q][2][2][ul][b]) + red[q][2][3][ul][b];
+                const float rr = sigmoidf_((ge[p][0] + gc[p][0]) + (gr + bh[p][0]));
+                const float z = sigmoidf_((ge[p][1] + gc[p][1]) + (gz + bh[p][1]));
+                const float n = tanhf((ge[p][2] + gc[p][2]) + rr * (gn + bh[p][2]));
+                const float hn = (1.0f - z) * n + z * hold[p];
+                hout[hi[p]] = hn;
+                if (hallp) hallp[4 * p] = hn;
+            }
         }
     } else {
-        // ---- MFMA waves: gate tile gt (r, z, n of the 16 units), K quarter kq; they also stage the state tiles
-        const int gt = (wave - 4) >> 2, kq = (wave - 4) & 3, mt = tid - 256;
-        float4 st[5];
-        big_stage_load(src + (size_t)g0 * t4, t4, mt, true, st);    // state before weights: vmcnt retires in order, so the
-        float4 wf[SW];                                               // staging barrier waits for the state only
+        // ---- MFMA waves: gate tile gt (r, z, n of the 16 units), K quarter kq
+        const int gt = (wave - 4) >> 2, kq = (wave - 4) & 3;
+        big_stage_load(src, t4, tid, true, st);              // state before weights: vmcnt retires in order, so the
+        float4 wf[SW];                                       // staging barrier waits for the state only
         load_wfrag<SW>(m.Wf_hh16, blk * 3 + gt, 4, kq, lane, wf);
         __builtin_amdgcn_sched_barrier(0);
-        big_stage_store(hs, t4, mt, true, st);
+        big_stage_store(hs, t4, tid, st);
         __syncthreads();
-        for (int i = 0; i < nt; ++i) {
-            const bool more = i + 1 < nt;
-            BIG_STAMP(tid == 256, i, 0);
-            big_stage_load(src + (size_t)(g0 + (i + 1) * G) * t4, t4, mt, more, st);   // the next tile streams in underneath these MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 *hp = hs + (size_t)(i & 1) * t4 + (size_t)kq * SW * 64 + lane;
+        big_stage_load(src + t4, t4, tid, nb > 1, st);       // tile 1 streams in underneath tile 0's MFMAs
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            if (qq == 1) {
+                big_stage_store(hs + t4, t4, tid, st);
+                __syncthreads();
+            }
+            const float4 *hp = hs + (size_t)qq * t4 + (size_t)kq * SW * 64 + lane;
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
@@ -997,13 +960,9 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
             }
             const f32x4 acc = a0 + a1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) red[i & 1][gt][kq][(lane >> 4) * 4 + k][lane & 15] = acc[k];
-            BIG_STAMP(tid == 256, i, 1);
-            big_stage_store(hs + (size_t)((i + 1) & 1) * t4, t4, mt, more, st);
-            BIG_STAMP(tid == 256, i, 2);
-            __syncthreads();
-            BIG_STAMP(tid == 256, i, 3);
+            for (int k = 0; k < 4; ++k) red[qq][gt][kq][(lane >> 4) * 4 + k][lane & 15] = acc[k];
         }
+        __syncthreads();
     }
 }
 
@@ -1828,33 +1787,19 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     return VQCPC_OK;
 }
 
-// Large-batch launch geometry.  fc2 + draw workgroups of a fused launch: four (class row group, tile chunk) teams each, at
-// most 8 tile chunks (a team then walks every 8th tile), so that they and the GRU workgroups -- one per CU, their LDS is
-// 141 KB -- are all resident at once on 256 CUs: (Hr/16) G + 32 <= 256 gives G = 4 tile groups at Hr = 896.
-static int big_fc2_blocks(int nbt) { return 4 * (nbt < 8 ? nbt : 8); }
-// LDS of ar_gru_big_kernel: two state tiles, two buffers of K-quarter partials, the candidate exchange of the cell-update waves
-static size_t big_lds_bytes(int Hr) {
-    return (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float) + (size_t)2 * 4 * 16 * sizeof(unsigned long long);
-}
-static int big_tile_groups(int Hr, int nbt, int n_fc2) {
-    int G = (256 - n_fc2) / (Hr / 16);
-    const int most = (nbt + 1) / 2;                  // at least two tiles per workgroup: the weights are fetched once per workgroup
-    G = G > most ? most : G;
-    return G < 1 ? 1 : G;
-}
-
 // tf: teacher-forced scan -- x_{t-1} comes from the inputs, so only the GRU step runs per sample (fc1 / fc2 follow
 // as batched GEMMs over the whole chunk, run_ar)
 static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int nbt, int n, bool tf, hipStream_t s) {
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
     // large-batch GRU kernel: >= big_min_tiles tiles in flight, Hr a multiple of 16, LDS fits
-    const size_t big_lds = big_lds_bytes(v->d.Hr);
+    const size_t big_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool big = v->big_min_tiles > 0 && nbt >= v->big_min_tiles && v->d.Hr % 16 == 0 && big_lds <= 160 * 1024;
     if (big && !v->big_attr_set) {
         switch (SW) {
 #define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
-                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
+                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
+                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
 #undef CASE
             default: break;
@@ -1866,22 +1811,22 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     // replay carries no fc2 blocks.
     // Level 2 (m.fused == 2): fc1 of step i-1 rides along too -- ONE launch per sample; the trailing launch is fc1 + fc2.
     const int rgs = v->d.Hr / 4, npass = (nbt + 1) / 2;
-    const int f2_full = big ? big_fc2_blocks(nbt) : (v->d.n_cls / 16) * nbt;
-    const int f1_full = (v->d.Hf / 8) * nbt;                                          // 8-row groups (level 2 runs on the small kernel only)
-    const int bigG = big_tile_groups(v->d.Hr, nbt, m.fused ? big_fc2_blocks(nbt) : 0);
+    const int f2_full = big ? (v->d.n_cls / 16) * nbt / 4 : (v->d.n_cls / 16) * nbt;
+    const int f1_full = big ? (v->d.Hf / 16) * nbt / 4 : (v->d.Hf / 8) * nbt;       // 16-row groups in teams of 4 / 8-row groups
     for (int i = 0; i < n; ++i) {
         const int nf = (m.fused && i > 0) ? f2_full : 0;
         const int n1 = (m.fused == 2 && i > 0) ? f1_full : 0;
         switch (SW) {
 #define CASE(k) case k: \
-            if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * bigG), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, nf, bigG); \
+            if (m.fused == 2 && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 2>), dim3(n1 + nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, n1, nf); \
             else if (m.fused == 2 && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 2>), dim3(n1 + nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, n1, nf); \
             else if (m.fused == 2) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 2>), dim3(n1 + nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, n1, nf); \
+            else if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, nf); \
             else if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
             else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
             else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
             else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
-            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3((v->d.Hr / 16) * bigG), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, bigG); \
+            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, 0); \
             else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
             else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
             if (tf || m.fused == 2) break; \
@@ -2095,9 +2040,10 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         m.abort_dev = (unsigned *)((char *)G.candg.p + cg_bytes);
         m.abort_host = abort_dev_ptr;
         {
-            const size_t big_lds = big_lds_bytes(Hr);
+            const size_t big_lds = (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
             const bool big = v->big_min_tiles > 0 && nb >= v->big_min_tiles && Hr % 16 == 0 && big_lds <= 160 * 1024;
-            m.fused = (v->fuse_fc2 && !tf && gmax[g] < (1 << 24)) ? (v->fuse_fc1 && !big ? 2 : 1) : 0;   // level 2: small kernel only
+            (void)big;
+            m.fused = (v->fuse_fc2 && !tf && gmax[g] < (1 << 24)) ? (v->fuse_fc1 ? 2 : 1) : 0;
         }
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
@@ -2203,11 +2149,10 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     const ArModel m = v->last_model;
     const int SW = v->d.Hr / 64;
     const dim3 blk(256);
-    const size_t tbig_lds = big_lds_bytes(v->d.Hr);
+    const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
     const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
-    const int nf = tbig ? big_fc2_blocks(c.nbt) : (v->d.n_cls / 16) * c.nbt;   // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
-    const int n1 = m.fused == 2 ? (v->d.Hf / 8) * c.nbt : 0;                   // ... and fc1 blocks in front of those
-    const int bigG = big_tile_groups(v->d.Hr, c.nbt, m.fused ? nf : 0);
+    const int nf = tbig ? (v->d.n_cls / 16) * c.nbt / 4 : (v->d.n_cls / 16) * c.nbt;   // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
+    const int n1 = m.fused == 2 ? (tbig ? (v->d.Hf / 16) * c.nbt / 4 : (v->d.Hf / 8) * c.nbt) : 0;   // ... and fc1 blocks in front of those
     int fresh = 0;                       // fused launches so far
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
@@ -2219,14 +2164,15 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
                 const int tl = 1 + 2 * ((which == 0 && m.fused) ? fresh++ % period : 0);   // that reuse steps, i.e. find their tags in place)
                 switch (SW) {
 #define CASE(k) case k: \
-                    if (which == 0 && m.fused && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * bigG), dim3(1024), tbig_lds, s, m, (const ArCall *)call, tl, c.nbt, nf, bigG); \
+                    if (which == 0 && m.fused == 2 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 2>), dim3(n1 + nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, tl, c.nbt, n1, nf); \
                     else if (which == 0 && m.fused == 2 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 2>), dim3(n1 + nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, tl, c.nbt, n1, nf); \
                     else if (which == 0 && m.fused == 2) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 2>), dim3(n1 + nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, n1, nf); \
-                    else if (which == 0 && m.fused && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
-                    else if (which == 0 && m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
-                    else if (which == 0 && m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
+                    else if (which == 0 && m.fused && !tbig && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
+                    else if (which == 0 && m.fused && !tbig && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
+                    else if (which == 0 && m.fused && !tbig) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
                     else if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
-                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3((v->d.Hr / 16) * bigG), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt, 0, bigG); \
+                    else if (which == 0 && tbig && m.fused) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
+                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
                     else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
                     else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
                     else if (c.nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
