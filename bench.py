@@ -283,10 +283,8 @@ def run_manifest(enc, voc, dev, n_utt, max_batch):
     dt = time.perf_counter() - t0
     samples = sum(int(w.numel()) for w in wavs)
     loop_ms, steps = voc.last_timing()                          # the decode loop alone (HIP events inside generate)
-    max_batch = driver.fit_slots([int(w.numel()) for w in wavs], max_batch)       # what convert_utterances used
     return {"workload": f"synthetic manifest (configs[4] stand-in): {n_utt} utterances, log-normal 1-10 s, "
-                        f"encoder in length buckets, decode by continuous batching over {max_batch} slots "
-                        f"(total / longest utterance, in whole tiles)",
+                        f"encoder in length buckets, decode by continuous batching over {max_batch} slots",
             "slots": max_batch,
             "utterances": n_utt, "audio_seconds": samples / 16000.0, "wall_s": dt,
             "samples_per_s": samples / dt, "realtime_factor_16k": samples / 16000.0 / dt,
@@ -328,7 +326,8 @@ def gru_roofline(voc, n_utt, step_us):
             "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "flop_per_launch": flop,
             "avg_launch_us": gru_us, "utterances_per_launch": per_launch,
-            "how": "HIP events on the launch stream around 2000 back-to-back launches (includes the ~1.5 us "
+            "how": "HIP events on the launch stream around 2000 back-to-back launches, each on the next sample step so that "
+                   "a fused launch waits for its own fc2 workgroups' candidates as in the decode loop (includes the ~1.5 us "
                    "dependent-launch boundary)",
             "launches_per_sample": 1 if whole else (2 if fused else 3),
             "other_kernels_us": {"ar_fc1_kernel" + (" (as its own launch, not on the fused path)" if whole else ""): fc1_us,

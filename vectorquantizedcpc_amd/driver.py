@@ -78,18 +78,6 @@ def encode_utterances(encoder: Encoder, mels: Sequence[torch.Tensor], want_conte
 
 
 @torch.no_grad()
-def fit_slots(lengths: Sequence[int], max_slots: int) -> int:
-    """Decode slots for continuous batching over utterances of ``lengths`` samples: a decode step costs about
-    a + b * slots, and the schedule cannot end before the longest utterance does, so slots beyond
-    total / longest only make every step dearer -- use the multiple of 16 (one MFMA tile) that covers
-    total / longest, at most ``max_slots``."""
-    longest = max(lengths) if lengths else 0
-    if longest <= 0 or max_slots <= 16:
-        return max(1, max_slots)
-    need = -(-sum(lengths) // longest)
-    return max(16, min(max_slots, -(-need // 16) * 16))
-
-
 def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.Tensor], speakers: Sequence[int],
                        seed: int, utt_ids: Optional[Sequence[int]] = None, max_batch: int = 64,
                        max_pad_frac: float = 0.25, slots: int = 0) -> List[torch.Tensor]:
@@ -97,8 +85,7 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
 
     ``slots`` > 0: continuous batching -- ONE decode call over all utterances with that many decode
     slots, each slot running utterances back to back (longest first), instead of one call per
-    length bucket; fewer slots are used when the utterances cannot keep that many busy (``fit_slots``).
-    The samples are the same either way (per-utterance sampling streams).
+    length bucket.  The samples are the same either way (per-utterance sampling streams).
     """
     dev = next(encoder.parameters()).device
     C = encoder.conf.in_channels
@@ -126,7 +113,7 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
         for i, cd in enumerate(codes):
             idx[i, : cd.numel()] = cd
         spk = torch.tensor([int(v) for v in speakers], device=dev)
-        vocoder.set_option("slots", fit_slots([2 * up * n for n in n_codes_all], slots))
+        vocoder.set_option("slots", slots)
         try:
             wav = vocoder.generate(idx, spk, n_codes=n_codes_all, seed=seed, utt_ids=utt_ids)
         finally:
