@@ -393,15 +393,19 @@ __device__ __forceinline__ void vq_take(const f32x4 &acc, int code, float e2, co
 struct VqSmem {
     float xs[16][68];
     float x2s[16];
-    float cd[4][16];
-    int cj[4][16];
+    float cd[8][16];
+    int cj[8][16];
     int best[16];
 };
 __device__ __forceinline__ void vq_rows16(VqSmem &sm, int r0, int N, const float4 *__restrict__ Ef, const float *__restrict__ E,
                                           const float *__restrict__ e2, int n_emb, int64_t *__restrict__ idx,
-                                          float *__restrict__ zq, int tid, const float4 (&f0_in)[4], const float4 (&f1_in)[4]) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int tpw = n_emb / 64, t0 = wave * tpw;                       // 16-code tiles per wave, this wave's first
+                                          float *__restrict__ zq, int tid, const float4 (&f0_in)[4], const float4 (&f1_in)[4],
+                                          int nwv = 4) {
+    // nwv = waves that search (4, or 8 of a 512-thread workgroup when the tiles divide); waves beyond only keep the two
+    // barriers company
+    const bool active = (tid >> 6) < nwv;                              // wave-uniform
+    const int lane = tid & 63, wave = active ? tid >> 6 : 0;
+    const int tpw = active ? n_emb / (16 * nwv) : 0, t0 = wave * tpw;  // 16-code tiles per wave, this wave's first
     float4 f0[4], f1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { f0[q] = f0_in[q]; f1[q] = f1_in[q]; }
@@ -460,21 +464,20 @@ __device__ __forceinline__ void vq_rows16(VqSmem &sm, int r0, int N, const float
         VQ_DPP_MIN(0x4E)            // quad_perm [2,3,0,1]
         VQ_DPP_MIN(0x141)           // row_half_mirror
         VQ_DPP_MIN(0x140)           // row_mirror
-        if ((lane & 15) == 0) { sm.cd[wave][4 * (lane >> 4) + r] = bd[r]; sm.cj[wave][4 * (lane >> 4) + r] = bj[r]; }
+        if (active && (lane & 15) == 0) { sm.cd[wave][4 * (lane >> 4) + r] = bd[r]; sm.cj[wave][4 * (lane >> 4) + r] = bj[r]; }
     }
 #undef VQ_DPP_MIN
     __syncthreads();
     if (tid < 16) {
         float d = sm.cd[0][tid];
         int j = sm.cj[0][tid];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < nwv; ++w)
             if (sm.cd[w][tid] < d) { d = sm.cd[w][tid]; j = sm.cj[w][tid]; }
         sm.best[tid] = j;
         if (r0 + tid < N) idx[r0 + tid] = j;
     }
     __syncthreads();
-    {
+    if (tid < 256) {
         const int row = tid >> 4, c4 = tid & 15;                       // F.embedding gather (model.py:113)
         if (r0 + row < N) ((float4 *)zq)[(size_t)(r0 + row) * 16 + c4] = ((const float4 *)E)[(size_t)sm.best[row] * 16 + c4];
     }
@@ -542,23 +545,30 @@ struct FusedP {
 
 // One GEMM stage for this wave: tile (LDS, 16 rows x K) x NT column tiles starting at ct0.  tot = fold over K blocks of
 // kcq q-steps (16 k each) of zero-started chains: first block (bias ? bias + chain : chain), later blocks tot + chain.
-// The first three q-steps' fragments of a stage, requested ahead of time (under the previous stage's epilogue and
+// The first D-1 q-steps' fragments of a stage, requested ahead of time (under the previous stage's epilogue and
 // LayerNorm, when the MFMA pipe would otherwise wait for the first bytes of the next weight matrix).
-template <int NT>
-__device__ __forceinline__ void rows16_prefetch(const float4 *__restrict__ Wf, int ct0, int nq, float4 (&fr)[4][NT], int lane) {
+// D = depth of the fragment ring (a power of two): fragments are requested D-1 q-steps (of 0.43 us of MFMAs at NT = 8)
+// before their MFMAs.  The weight stream is latency x bytes-in-flight bound: with D = 4 a wave has 24 KB in flight and
+// a workgroup pulls 44 GB/s -- alone on the chip as well as among 255 others -- against the 75 GB/s its MFMAs consume.
+// q_off / nq_all: the stage covers q-steps [q_off, q_off + nq) of a fragment array holding nq_all per column tile (0: nq).
+template <int NT, int D>
+__device__ __forceinline__ void rows16_prefetch(const float4 *__restrict__ Wf, int ct0, int nq, float4 (&fr)[D][NT], int lane,
+                                                int q_off = 0, int nq_all = 0) {
+    const int qs = nq_all ? nq_all : nq;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < D - 1; ++u)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fr[u][j] = Wf[(((size_t)(ct0 + j) * nq) + (u < nq ? u : nq - 1)) * 64 + lane];
+        for (int j = 0; j < NT; ++j) fr[u][j] = Wf[(((size_t)(ct0 + j) * qs) + q_off + (u < nq ? u : nq - 1)) * 64 + lane];
 }
 
-template <int NT>
+template <int NT, int D>
 __device__ __forceinline__ void rows16_gemm(const float *tile, const float4 *__restrict__ Wf, int ct0, int nq, int kcq,
-                                            const float *__restrict__ bias, f32x4 (&tot)[NT], int lane, float4 (&fr)[4][NT]) {
+                                            const float *__restrict__ bias, f32x4 (&tot)[NT], int lane, float4 (&fr)[D][NT],
+                                            int q_off = 0, int nq_all = 0) {
     const float4 *wp[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wp[j] = Wf + ((size_t)(ct0 + j) * nq) * 64 + lane;
-    const float *arow = tile + (lane & 15) * FE_LD + (lane >> 4);
+    for (int j = 0; j < NT; ++j) wp[j] = Wf + ((size_t)(ct0 + j) * (nq_all ? nq_all : nq) + q_off) * 64 + lane;
+    const float *arow = tile + (lane & 15) * FE_LD + (lane >> 4) + 16 * q_off;
     float an[4] = {arow[0], arow[4], arow[8], arow[12]};
     f32x4 acc[NT];
     float bv[NT];
@@ -569,13 +579,14 @@ __device__ __forceinline__ void rows16_gemm(const float *tile, const float4 *__r
         bv[j] = bias ? bias[16 * (ct0 + j) + (lane & 15)] : 0.f;
     }
     bool first = true;
-    for (int q0 = 0; q0 < nq; q0 += 4) {
+    for (int q0 = 0; q0 < nq; q0 += D) {                             // nq is a multiple of 4; D = 8 walks it in halves
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < D; ++u) {
             const int q = q0 + u;
-            const int qp = q + 3 < nq ? q + 3 : nq - 1;
+            if (D > 4 && q >= nq) break;                             // wave-uniform
+            const int qp = q + D - 1 < nq ? q + D - 1 : nq - 1;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fr[(u + 3) & 3][j] = wp[j][(size_t)qp * 64];
+            for (int j = 0; j < NT; ++j) fr[(u + D - 1) & (D - 1)][j] = wp[j][(size_t)qp * 64];
             const float a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
             const int qn = q + 1 < nq ? q + 1 : q;
             an[0] = arow[16 * qn]; an[1] = arow[16 * qn + 4]; an[2] = arow[16 * qn + 8]; an[3] = arow[16 * qn + 12];
@@ -589,17 +600,17 @@ __device__ __forceinline__ void rows16_gemm(const float *tile, const float4 *__r
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, fr[u][j].w, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if ((q0 + 4) % kcq == 0) {                                   // end of a K block (kcq is a multiple of 4)
+            if ((u & 3) == 3 && (q + 1) % kcq == 0) {                // end of a K block (kcq is a multiple of 4)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+                for (int j = 0; j < NT; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    tot[j][r] = first ? (bias ? bv[j] + acc[j][r] : acc[j][r]) : tot[j][r] + acc[j][r];
-                    acc[j][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        tot[j][r] = first ? (bias ? bv[j] + acc[j][r] : acc[j][r]) : tot[j][r] + acc[j][r];
+                        acc[j][r] = 0.f;
+                    }
                 }
+                first = false;
             }
-            first = false;
         }
     }
 }
@@ -614,17 +625,19 @@ __device__ __forceinline__ void rows16_store(float *tile, const f32x4 (&tot)[NT]
 }
 
 // LayerNorm(512) + ReLU of the tile in place: the half-wave-per-row procedure of ln512_kernel (ATen's order).  A half-wave
-// owns rows r and r + 8 and runs their two (serial, latency-bound) moment cascades interleaved; it then normalises both.
+// owns rows r and r + 8 and runs their two (serial, latency-bound) moment cascades interleaved; it then normalises both
+// (R = 2, 256-thread workgroups); with 512 threads every half-wave has one row (R = 1).
+template <int R>
 __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__restrict__ g, const float *__restrict__ b,
                                                  float eps, const LnConst &k, int tid) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, ll = lane & 31;
     const int chunk = ll >> 3, l = ll & 7;
-    float *x[2] = {tile + (wave * 2 + half) * FE_LD, tile + (8 + wave * 2 + half) * FE_LD};
+    float *x[2] = {tile + (wave * 2 + half) * FE_LD, tile + ((R == 2 ? 8 : 0) + wave * 2 + half) * FE_LD};
     float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float xv = x[r][(chunk * 16 + j) * 8 + l];
             const float d = xv - m1[r];
             m1[r] = __builtin_fmaf(d, k.inv[j], m1[r]);
@@ -632,7 +645,7 @@ __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__res
         }
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {                                       // chunk 1 -> 0, 3 -> 2 (16 + 16 vectors)
+    for (int r = 0; r < R; ++r) {                                       // chunk 1 -> 0, 3 -> 2 (16 + 16 vectors)
         const float a1 = __shfl_down(m1[r], 8), a2 = __shfl_down(m2[r], 8);
         const float delta = a1 - m1[r];
         const float n1 = __builtin_fmaf(0.5f, delta, m1[r]);
@@ -640,7 +653,7 @@ __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__res
         m1[r] = n1;
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {                                       // (chunks 2, 3) -> (chunks 0, 1) (32 + 32 vectors)
+    for (int r = 0; r < R; ++r) {                                       // (chunks 2, 3) -> (chunks 0, 1) (32 + 32 vectors)
         const float a1 = __shfl_down(m1[r], 16), a2 = __shfl_down(m2[r], 16);
         const float delta = a1 - m1[r];
         const float n1 = __builtin_fmaf(0.5f, delta, m1[r]);
@@ -651,7 +664,7 @@ __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__res
 #pragma unroll
     for (int q = 0; q < 8; ++q) {                                       // the 8 vector lanes, serially
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float s1 = __shfl(m1[r], half * 32 + q), s2 = __shfl(m2[r], half * 32 + q);
             const float delta = s1 - M1[r];
             M1[r] = __builtin_fmaf(k.sc[q], delta, M1[r]);
@@ -660,7 +673,7 @@ __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__res
     }
     float mean[2], rstd[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < R; ++r) {
         mean[r] = M1[r];
         const float var = M2[r] / 512.0f;
         const float sd = (float)sqrt((double)(var + eps));              // both correctly rounded in fp32 (via fp64)
@@ -672,7 +685,7 @@ __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__res
         const float2 gv = *(const float2 *)(g + e);
         const float2 bb = *(const float2 *)(b + e);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float2 xv = *(const float2 *)(x[r] + e);
             float2 o;
             o.x = __builtin_fmaf((xv.x - mean[r]) * rstd[r], gv.x, bb.x);
@@ -686,21 +699,28 @@ __device__ __forceinline__ void rows16_layernorm(float *tile, const float *__res
 
 __device__ __forceinline__ bool rows16_dump(const FusedP &p, const float *tile, int stage, int r0, int tid) {
     if (p.stage != stage) return false;
-    for (int e = tid; e < 16 * 512; e += 256) {
+    for (int e = tid; e < 16 * 512; e += (int)blockDim.x) {
         const int row = e >> 9, col = e & 511;
         if (r0 + row < p.N) p.stage_out[(size_t)(r0 + row) * 512 + col] = tile[row * FE_LD + col];
     }
     return true;
 }
 
-__global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
+// 512 threads: eight waves of four column tiles, TWO per SIMD.  With one wave per SIMD (256 threads x eight tiles) the MFMA
+// pipe idles while that wave requests the next fragments, reads its A operands and folds K blocks -- each Linear took 18.5 us
+// for 13.7 us of MFMAs (tools/encoder_stage_times.py); a second wave fills those gaps, and LayerNorm has a half-wave per row.
+__global__ __launch_bounds__(512) void enc_fused_kernel(FusedP p) {
     __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
     __shared__ VqSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
     const int K0 = 4 * p.C;
+    constexpr int NT = 4, RD = 4;                        // column tiles per wave; fragment ring: 3 q-steps ahead (a ring of 8 --
+    f32x4 tot[NT];                                       // 7 ahead -- measured the same: the stream is not what the MFMAs wait for)
+    float4 fr[RD][NT];
+    rows16_prefetch<NT, RD>(p.conv_f, NT * wave, K0 / 16, fr, lane);      // the first conv fragments fly under the gather
 
     // ---- im2col gather of the 16 rows (model.py:65), k order of the reference back end (fetch_a)
-    for (int e = tid; e < 16 * K0; e += 256) {
+    for (int e = tid; e < 16 * K0; e += 512) {
         const int i = e & 15, kidx = e >> 4, m = r0 + i;
         int c, tap;
         if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
@@ -714,53 +734,66 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(FusedP p) {
     }
     __syncthreads();
 
-    f32x4 tot[8];
-    float4 fr[4][8];
-    rows16_prefetch<8>(p.conv_f, 8 * wave, K0 / 16, fr, lane);
-    rows16_gemm<8>(tile, p.conv_f, 8 * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane, fr);
-    if (p.stage != 0) rows16_prefetch<8>(p.fc_f[0], 8 * wave, 32, fr, lane);          // under the store + LayerNorm below
+    rows16_gemm<NT, RD>(tile, p.conv_f, NT * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane, fr);
+    if (p.stage != 0) rows16_prefetch<NT, RD>(p.fc_f[0], NT * wave, 32, fr, lane);    // under the store + LayerNorm below
     __syncthreads();                                     // every wave has read its A operands
-    rows16_store<8>(tile, tot, 8 * wave, lane);
+    rows16_store<NT>(tile, tot, NT * wave, lane);
     __syncthreads();
     if (rows16_dump(p, tile, 0, r0, tid)) return;
 
     // ---- seg-FC stack (model.py:46-55)
-    rows16_layernorm(tile, p.ln_g[0], p.ln_b[0], p.eps, p.lnc, tid);
+    rows16_layernorm<1>(tile, p.ln_g[0], p.ln_b[0], p.eps, p.lnc, tid);
     __syncthreads();
     if (rows16_dump(p, tile, 1, r0, tid)) return;
     for (int l = 0; l < 4; ++l) {
-        rows16_gemm<8>(tile, p.fc_f[l], 8 * wave, 32, 16, nullptr, tot, lane, fr);
-        if (l < 3) rows16_prefetch<8>(p.fc_f[l + 1], 8 * wave, 32, fr, lane);
+        rows16_gemm<NT, RD>(tile, p.fc_f[l], NT * wave, 32, 16, nullptr, tot, lane, fr);
+        if (l < 3) rows16_prefetch<NT, RD>(p.fc_f[l + 1], NT * wave, 32, fr, lane);
         __syncthreads();
-        rows16_store<8>(tile, tot, 8 * wave, lane);
+        rows16_store<NT>(tile, tot, NT * wave, lane);
         __syncthreads();
         if (rows16_dump(p, tile, 2 + 2 * l, r0, tid)) return;
-        rows16_layernorm(tile, p.ln_g[l + 1], p.ln_b[l + 1], p.eps, p.lnc, tid);
+        rows16_layernorm<1>(tile, p.ln_g[l + 1], p.ln_b[l + 1], p.eps, p.lnc, tid);
         __syncthreads();
         if (rows16_dump(p, tile, 3 + 2 * l, r0, tid)) return;
     }
 
-    // ---- encoder.14: 512 -> 64 with bias; one 16-column tile per wave; the VQ codebook tiles stream in underneath
-    const int tpw = p.n_emb / 64, t0 = wave * tpw;
-    float4 f0[4], f1[4];
-    vq_load_tile(p.Ef, t0, lane, f0);
-    vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
+    // ---- encoder.14: 512 -> 64 with bias: four 16-column tiles.  The reference's fold (bias + c0) + c1 has two independent
+    // zero-started chains (k < 256, k >= 256): wave w runs c0 of tile w, wave w + 4 runs c1 -- half the dependent MFMA chain
+    // each -- and hands it over through LDS.  The VQ codebook tiles stream in underneath.
+    const int ctw = wave & 3, kh = wave >> 2;
+    const int nwv = p.n_emb % 128 == 0 ? 8 : 4;          // waves of the VQ search
+    const int tpw = p.n_emb / (16 * nwv), t0 = (wave < nwv ? wave : 0) * tpw;
+    float4 f0[4] = {}, f1[4] = {};
+    if (wave < nwv) {
+        vq_load_tile(p.Ef, t0, lane, f0);
+        vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
+    }
     f32x4 zt[1];
     float4 fr1[4][1];
-    rows16_prefetch<1>(p.out_f, wave, 32, fr1, lane);
-    rows16_gemm<1>(tile, p.out_f, wave, 32, 16, p.out_b, zt, lane, fr1);
+    rows16_prefetch<1, 4>(p.out_f, ctw, 16, fr1, lane, 16 * kh, 32);
+    rows16_gemm<1, 4>(tile, p.out_f, ctw, 16, 16, kh == 0 ? p.out_b : nullptr, zt, lane, fr1, 16 * kh, 32);
+    float (*c1s)[68] = (float (*)[68])tile;              // the activation tile is dead once every wave is past its chain
+    __syncthreads();
+    if (kh == 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
-        sm.xs[row][col] = zt[0][r];
-        if (p.z_pre && r0 + row < p.N) p.z_pre[(size_t)(r0 + row) * 64 + col] = zt[0][r];
+        for (int r = 0; r < 4; ++r) c1s[4 * (lane >> 4) + r][16 * ctw + (lane & 15)] = zt[0][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r, col = 16 * ctw + (lane & 15);
+            const float z = zt[0][r] + c1s[row][col];
+            sm.xs[row][col] = z;
+            if (p.z_pre && r0 + row < p.N) p.z_pre[(size_t)(r0 + row) * 64 + col] = z;
+        }
     }
     __syncthreads();
     if (p.stage == 10) return;                           // z_pre is the stage output
     // ---- VQ (model.py:103-115)
     if (tid < 16) sm.x2s[tid] = r0 + tid < p.N ? sumsq64(&sm.xs[tid][0]) : 0.f;
     __syncthreads();
-    vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1);
+    vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1, nwv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -867,8 +900,8 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
         else {                                                            // other channel counts: the generic fold
             f32x4 t1[1];
             float4 fr1[4][1];
-            rows16_prefetch<1>(p.conv_f, ct, nq, fr1, lane);
-            rows16_gemm<1>(tile, p.conv_f, ct, nq, p.conv_mode == 1 ? nq : 4, nullptr, t1, lane, fr1);
+            rows16_prefetch<1, 4>(p.conv_f, ct, nq, fr1, lane);
+            rows16_gemm<1, 4>(tile, p.conv_f, ct, nq, p.conv_mode == 1 ? nq : 4, nullptr, t1, lane, fr1);
             tot = t1[0];
         }
 #pragma unroll
@@ -903,7 +936,7 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
             *(float2 *)(d + 2) = make_float2(av[n].z, av[n].w);
         }
         __syncthreads();
-        rows16_layernorm(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
+        rows16_layernorm<2>(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
         __syncthreads();
         const f32x4 acc = rows16_gemm_pre<1, 16>(tile + 256 * kh, wh, ct, nullptr, lane);      // k in [256 kh, 256 kh + 256)
         if (kh == 1) {
@@ -930,7 +963,7 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
         *(float2 *)(d + 2) = make_float2(av[n].z, av[n].w);
     }
     __syncthreads();
-    rows16_layernorm(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
+    rows16_layernorm<2>(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
     __syncthreads();
     const int tpw = p.n_emb / 64, t0 = wave * tpw;
     float4 f0[4], f1[4];
@@ -1182,7 +1215,7 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
         }
         hipLaunchKernelGGL(enc_split_kernel, dim3(1, ntiles), dim3(256), 0, s, p, 5, (const float *)a, (float *)nullptr);
     } else {
-        hipLaunchKernelGGL(enc_fused_kernel, dim3(ntiles), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(enc_fused_kernel, dim3(ntiles), dim3(512), 0, s, p);
     }
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
