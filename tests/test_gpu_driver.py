@@ -56,6 +56,30 @@ def test_convert_utterances_equals_batch1_calls():
         assert torch.equal(got[i], wav[0]), i
 
 
+def test_manifest_workload_continuous_batching():
+    """BASELINE configs[4]'s shape (bench.py's `manifest` leg) at test size: 96 ragged utterances of 1-4 s through the
+    length-bucketed encoder and ONE continuous-batching decode over 48 slots (three tiles; every slot runs two utterances on
+    average).  Every waveform has its utterance's length, is finite and in range and differs from its neighbours'; a spread
+    of utterances equals the batch-1 calls of convert.py:72-77 bit for bit."""
+    import bench
+    enc, voc = models()
+    frames, spk = bench.synthetic_manifest(96)
+    frames = [min(f, 400) for f in frames]                                   # 1-4 s: about 4 M samples in all
+    mels = [synth.mel(f"man/{i % 8}", 1, max(frames))[0][:, :f].contiguous() for i, f in enumerate(frames)]
+    wavs = driver.convert_utterances(enc, voc, mels, spk, seed=13, max_batch=64, max_pad_frac=0.15, slots=48)
+    assert len(wavs) == 96
+    for i, w in enumerate(wavs):
+        assert w.shape == (320 * driver.out_frames(frames[i]),), i
+        assert torch.isfinite(w).all() and float(w.abs().max()) <= 1.0, i
+    assert not torch.equal(wavs[0][:16000], wavs[1][:16000])
+    ms, steps = voc.last_timing()
+    assert steps >= max(int(w.numel()) for w in wavs) and ms > 0
+    for i in (0, 17, 48, 95):
+        idx = enc.encode_indices(mels[i][None].cuda())
+        one = voc.generate(idx, torch.tensor([spk[i]], device="cuda"), seed=13, utt_ids=[i])
+        assert torch.equal(wavs[i], one[0]), i
+
+
 def test_cli_encode_and_convert_end_to_end(tmp_path):
     """encode.py / convert.py equivalents on a tiny synthetic dataset: files written in the
     reference's formats, contents equal to direct calls."""

@@ -101,6 +101,27 @@ def test_context_and_forward_stats(name, golden_dir):
     assert abs(float(ppl) - float(g["perplexity"])) <= 1e-4 * float(g["perplexity"])
 
 
+def test_single_utterance_context_resident_scan_same_bits():
+    """encode.py:42-46 encodes ONE utterance at a time: its context LSTM (model.py:57) then runs as one resident kernel
+    (32 workgroups on one XCD, in-kernel exchanges of h_t) instead of one launch per time step.  Same bits as the launches,
+    for 1, 7 and 100 time steps; <= 1e-6 against the oracle; a second call on the same handle gives the same again."""
+    enc, sd = encoder_for("init", "init")
+    for T in (2, 14, 200):
+        mel = synth.mel("ctx1/%d" % T, 1, T)
+        melc = mel.cuda()
+        _, c_res, _ = enc.encode(melc)
+        _, c_res2, _ = enc.encode(melc)
+        enc.set_option("persistent_context", 0)
+        try:
+            _, c_steps, _ = enc.encode(melc)
+        finally:
+            enc.set_option("persistent_context", 1)
+        assert c_res.shape == (1, T // 2, 256)
+        assert torch.equal(c_res, c_steps) and torch.equal(c_res, c_res2), T
+        want = oracle.encoder_encode(sd, mel.numpy())["c"]
+        assert np.abs(c_res.cpu().numpy() - want).max() <= 1e-6, T
+
+
 def test_both_conv_backends_match_oracle():
     enc, sd = encoder_for("init", "init")
     mel = synth.mel("convmodes", 1, 64)

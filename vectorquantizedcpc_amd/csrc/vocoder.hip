@@ -229,14 +229,21 @@ __global__ void add_vec_kernel(const float *a, const float *b, float *o, int n) 
 struct LstmPlan {
     int D, H;
     float *w_ih = nullptr, *bias = nullptr, *Wf = nullptr;
-    DevBuf gi, hbuf, cbuf;
+    float *w_hh = nullptr;               // plain [4H][H] copy for the persistent single-utterance scan
+    DevBuf gi, hbuf, cbuf, px;
+    unsigned *abort_host = nullptr;      // pinned, host-mapped: a timed-out exchange of the persistent scan is reported by the next call
+    int persistent = -1;                 // -1 auto (one utterance, H = 256), 0 off
+    bool pending = false;                // a persistent scan may have raised the flag
 };
+static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s);
 void vq_lstm_plan_destroy(LstmPlan *p) {
     if (!p) return;
     if (p->w_ih) (void)hipFree(p->w_ih);
     if (p->bias) (void)hipFree(p->bias);
     if (p->Wf) (void)hipFree(p->Wf);
-    p->gi.release(); p->hbuf.release(); p->cbuf.release();
+    if (p->w_hh) (void)hipFree(p->w_hh);
+    if (p->abort_host) (void)hipHostFree(p->abort_host);
+    p->gi.release(); p->hbuf.release(); p->cbuf.release(); p->px.release();
     delete p;
 }
 int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int D, int H,
@@ -251,8 +258,13 @@ int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih,
     hipLaunchKernelGGL(add_vec_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, 0, b_ih, b_hh, p->bias, 4 * H);
     HIP_TRY(hipGetLastError());
     TRY(build_wfrag(w_hh, H, H / 4, H, 4, 4, H, &p->Wf));
+    HIP_TRY(hipMalloc((void **)&p->w_hh, (size_t)4 * H * H * sizeof(float)));
+    HIP_TRY(hipMemcpy(p->w_hh, w_hh, (size_t)4 * H * H * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipHostMalloc((void **)&p->abort_host, 64, hipHostMallocMapped));
+    *p->abort_host = 0u;
     return VQCPC_OK;
 }
+int vq_lstm_set_persistent(LstmPlan *p, int value) { p->persistent = value; return VQCPC_OK; }
 int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream_t s) {
     const int H = p->H, nbt = (B + 15) / 16;
     TRY(p->gi.reserve((size_t)B * T * 4 * H * sizeof(float)));
@@ -260,6 +272,19 @@ int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream
     TRY(p->hbuf.reserve(2 * hsz));
     TRY(p->cbuf.reserve(hsz));
     TRY(vq_gemm_chain(x, p->D, p->w_ih, p->bias, p->gi.as<float>(), 4 * H, B * T, 4 * H, p->D, p->D, s));
+    if (p->pending) {                    // did an earlier persistent scan report a timeout?  (no HIP call: host-mapped word)
+        p->pending = false;
+        if (*(volatile unsigned *)p->abort_host != 0u) {
+            *p->abort_host = 0u;
+            p->persistent = 0;
+            vq_set_error("encoder LSTM: an in-kernel exchange of the persistent scan timed out; this handle now uses one launch "
+                         "per time step");
+            return VQCPC_ERR_HIP;
+        }
+    }
+    // encode.py:42-46 calls encode() on ONE utterance at a time: that scan is a chain of T dependent 256-value exchanges,
+    // 3.6 us each as launches, < 1 us each inside one resident kernel
+    if (p->persistent != 0 && B == 1 && H == 256 && T >= 1) return lstm_persist_launch(p, T, out, s);
     HIP_TRY(hipMemsetAsync(p->hbuf.p, 0, 2 * hsz, s));
     HIP_TRY(hipMemsetAsync(p->cbuf.p, 0, hsz, s));
     SeqP q{};
@@ -1162,6 +1187,111 @@ __device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, int per_blk, un
         }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent scan of the encoder LSTM for ONE utterance (model.py:57 as encode.py:42-46 calls it: batch 1).
+// The input projection is hoisted (Gi), so a time step is W_hh h_{t-1} (1024 x 256) + the cell update + an all-to-all of
+// 256 values.  32 workgroups of 256 threads stay resident, each with 8 hidden units = 32 gate rows in registers (8 chain
+// lanes per row, the chains and their combination exactly those of seq_step_kernel's MFMAs -> the same bits), and exchange
+// h_t as {tag, value} granules, one 128-B line per workgroup.
+// All 32 sit on ONE XCD: the grid is 8 x 32 and only every 8th workgroup works (workgroup id % 8 is the XCD:
+// profiles/r02_xcd_exchange_microbench.csv).  Parties that share an L2 can publish with plain stores -- the write-through
+// L1 leaves them in that L2, where sc1 loads find them: 0.41 us per exchange against 1.2 us through memory.  The placement
+// is CHECKED, not assumed: the workers first exchange their XCC_ID with agent-scope stores, and fall back to those for the
+// scan unless all ids agree.  Every wait is bounded; a timeout raises a host-mapped flag the next call reports.
+// ------------------------------------------------------------------------------------------
+#define LP_NW 32          // workers
+#define LP_UPB 8          // hidden units per worker (H = 256)
+struct LstmPersistP {
+    const float *w_hh;    // [4H][H]
+    const float *Gi;      // [T][4H]  W_ih x_t + b_ih + b_hh
+    float *out;           // [T][H]
+    u64 *g;               // [2][LP_NW][PS_PAD] granules: h_t goes to buffer t & 1 -- with ONE exchange per step a fast worker
+                          // publishes h_t while a slow one still sweeps h_{t-1}; it cannot reach h_{t+1} before that sweep ended
+    unsigned *abort_flag;
+    int T;
+};
+template <bool LOCAL>
+__device__ __forceinline__ void lp_store(u64 *p, u64 v) {
+    if (LOCAL) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");    // plain: stays in this XCD's L2
+    else ps_store(p, v);
+}
+__global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistP p) {
+    constexpr int H = 256;
+    if (blockIdx.x % 8 != 0) return;
+    const int blk = blockIdx.x / 8, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float hbuf[H];             // h_{t-1}, ps_perm order
+    __shared__ float gsum[4 * LP_UPB];                                  // W_hh h_{t-1} of the owned rows [gate][unit]
+    // ---- resident weights: row r = gate * 8 + unit, 8 chain lanes per row (as ar_persist_kernel)
+    const int row_local = tid >> 3, gate = row_local / LP_UPB, ul = row_local % LP_UPB;
+    const int kw = (lane & 7) >> 1, c0 = lane & 1;
+    float w[8 * 4];
+    ps_load_weights<4>(p.w_hh + (size_t)(gate * H + LP_UPB * blk + ul) * H, kw, c0, w);
+    const int unit = LP_UPB * blk + (tid < LP_UPB ? tid : 0);
+    const u64 *gw = p.g + (size_t)(8 * wave) * PS_PAD;                  // this wave sweeps granules 64 wave .. 64 wave + 63
+    // ---- are all workers on one XCD?  (ids exchanged through memory: agent-scope stores, slot 8 of every line)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (tid == 0) ps_store(p.g + (size_t)blk * PS_PAD + 8, ((u64)0xC0DEu << 32) | xcc);
+    bool dead = false, local = true;
+    {
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            const u64 x = ps_load(p.g + (size_t)(lane & 31) * PS_PAD + 8);
+            if (__all((unsigned)(x >> 32) == 0xC0DEu)) { local = __all((unsigned)x == xcc); break; }
+            if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
+                                       __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+                if (lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    float cst = 0.f;                                                    // cell state of unit `tid` (tid < 8)
+    float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, gi3 = 0.f;
+    if (tid < LP_UPB) { const float *gp = p.Gi + unit; gi0 = gp[0]; gi1 = gp[H]; gi2 = gp[2 * H]; gi3 = gp[3 * H]; }
+    for (int t = 0; t < p.T; ++t) {
+        // ---- h_{t-1} from everyone (zero at t = 0)
+        float hv = 0.f;
+        if (t > 0 && !dead) {
+            unsigned v[1];
+            if (ps_sweep<1>(gw + (size_t)((t - 1) & 1) * LP_NW * PS_PAD, lane, LP_UPB, (unsigned)t, v, p.abort_flag)) hv = __uint_as_float(v[0]);
+            else dead = true;
+        }
+        hbuf[ps_perm(tid)] = hv;
+        ps_barrier();
+        const float acc = ps_chain<4>(w, (const float4 *)hbuf, kw, c0);
+        const float v = ps_combine(acc, lane);
+        if ((lane & 7) == 0) gsum[row_local] = v;
+        ps_barrier();
+        if (tid < LP_UPB) {
+            const float ig = sigmoidf_(gi0 + gsum[tid]), fg = sigmoidf_(gi1 + gsum[LP_UPB + tid]);
+            const float gg = tanhf(gi2 + gsum[2 * LP_UPB + tid]), og = sigmoidf_(gi3 + gsum[3 * LP_UPB + tid]);
+            cst = fg * cst + ig * gg;
+            const float hn = og * tanhf(cst);
+            const u64 gr = ((u64)(unsigned)(t + 1) << 32) | __float_as_uint(hn);
+            u64 *dst = p.g + ((size_t)(t & 1) * LP_NW + blk) * PS_PAD + tid;
+            if (local) lp_store<true>(dst, gr);
+            else lp_store<false>(dst, gr);
+            p.out[(size_t)t * H + unit] = hn;
+            if (t + 1 < p.T) { const float *gp = p.Gi + (size_t)(t + 1) * 4 * H + unit; gi0 = gp[0]; gi1 = gp[H]; gi2 = gp[2 * H]; gi3 = gp[3 * H]; }
+        }
+    }
+}
+static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s) {
+    const size_t bytes = (size_t)2 * LP_NW * PS_PAD * sizeof(u64);
+    TRY(p->px.reserve(bytes));
+    HIP_TRY(hipMemsetAsync(p->px.p, 0, bytes, s));
+    LstmPersistP q{};
+    q.w_hh = p->w_hh; q.Gi = p->gi.as<float>(); q.out = out; q.g = p->px.as<u64>(); q.T = T;
+    HIP_TRY(hipHostGetDevicePointer((void **)&q.abort_flag, p->abort_host, 0));
+    hipLaunchKernelGGL(lstm_persist_kernel, dim3(8 * LP_NW), dim3(256), 0, s, q);
+    HIP_TRY(hipGetLastError());
+    p->pending = true;
+    return VQCPC_OK;
 }
 
 template <int SW>     // Hr = 64 SW; each of the 64 workgroups owns SW hidden units; Hf = n_cls = 256
