@@ -104,8 +104,6 @@ int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int
  * column-split launches (one per Linear, LayerNorm applied on load, VQ in the last) for calls too small to fill the chip
  * with whole-row workgroups; 0 = the layered kernels, one launch per module of model.py:43-55; -1 (default) = 2 for calls
  * of up to `split_max_tiles` (default 64) 16-row tiles, else 1; 0 when 4 * in_channels > 512.
- * resident (default 1): calls of up to 8 row tiles (128 output frames: one utterance) run the six split layers in ONE
- * launch whose 16 column workgroups per row tile stay resident and hand the rows over in-kernel; 0 = six launches.
  * persistent_context (default 1): the context LSTM (model.py:57) of a ONE-utterance call -- encode.py:42-46's batch 1 --
  * runs as one resident kernel with in-kernel exchanges of h_t instead of one launch per time step; 0 = always launches.
  * Same bits either way. */

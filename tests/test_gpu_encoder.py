@@ -182,29 +182,23 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("name", ["c2_init", "odd_2x33", "c1_init", "c2_random_data"])
 def test_layered_and_fused_front_ends_same_bits(name, golden_dir):
-    """The one-launch fused front end (1), the column-split schedule for small calls (2: one resident launch up to 8 row tiles,
-    else -- and with `resident` off -- six launches) and the layered kernels (0, one launch per module) are schedules of the
-    same rounding sequence: every stage, z, z_pre and the indices
+    """The one-launch fused front end (1), the six column-split launches for small calls (2) and the layered kernels
+    (0, one launch per module) are three schedules of the same rounding sequence: every stage, z, z_pre and the indices
     carry the same bits, and they equal the reference's SHAs.  (Default: 2 up to 64 row tiles, else 1.)"""
     g, enc, sd, mel = load_case(name, golden_dir)
     melc = mel.cuda()
     outs = {}
     try:
-        for fused in (1, 2, 3, 0):                       # 3 = the split schedule as six launches (resident form off)
-            enc.set_option("fused", min(fused, 2))
-            enc.set_option("resident", 0 if fused == 3 else 1)
+        for fused in (1, 2, 0):
+            enc.set_option("fused", fused)
             z, c, idx = enc.encode(melc)
-            z_again, _, idx_again = enc.encode(melc)     # the resident kernel's flags are reset per call
-            assert torch.equal(idx, idx_again) and torch.equal(z, z_again)
             stages = [enc.stage(melc, s) for s in range(11)]
             outs[fused] = (z, idx, stages)
     finally:
         enc.set_option("fused", -1)
-        enc.set_option("resident", 1)
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][1], outs[1][1]) and torch.equal(outs[3][1], outs[1][1])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][1], outs[1][1])
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
     assert torch.equal(outs[2][0].view(torch.int32), outs[1][0].view(torch.int32))
-    assert torch.equal(outs[3][0].view(torch.int32), outs[1][0].view(torch.int32))
     for s in range(11):
         assert torch.equal(outs[0][2][s].view(torch.int32), outs[1][2][s].view(torch.int32)), s
     assert sha(outs[1][0].cpu().numpy()) == str(g["sha_z"])

@@ -850,8 +850,8 @@ __device__ __forceinline__ f32x4 rows16_gemm_pre(const float *tile, const float4
     return tot;
 }
 
-// The three layer kinds of the split schedule for column group `cg` of the row tile at r0 (bodies of enc_split_kernel and
-// enc_resident_kernel): conv (layer 0), Linear l = 1..4 (LayerNorm l-1 on load), encoder.14 + VQ (LayerNorm 4 on load).
+// The three layer kinds of the split schedule for column group `cg` of the row tile at r0 (bodies of enc_split_kernel):
+// conv (layer 0), Linear l = 1..4 (LayerNorm l-1 on load), encoder.14 + VQ (LayerNorm 4 on load).
 __device__ __forceinline__ void split_conv(const FusedP &p, float *__restrict__ out, int cg, int r0, float *tile) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K0 = 4 * p.C;
@@ -1003,117 +1003,8 @@ __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, con
     else split_tail(p, in, r0, tile, sm);
 }
 
-// ------------------------------------------------------------------------------------------
-// Resident form of the split schedule for calls of up to 8 row tiles (128 frames = 2.56 s: a single utterance, encode.py:42-46).
-// The six launches above are boundary-bound (1.5 us between dependent launches + a cold start behind an emptied L2, 8.5 us
-// per layer for ~1 us of MFMAs).  Here the same 16 column workgroups per row tile stay resident through all six layers and
-// hand the raw rows over in-kernel: a workgroup stores its 16 x 32 slice, waits for the stores' acknowledgements, raises a
-// {tag = layer} granule; the consumers sweep the 16 granules of their row tile, invalidate L1 and read the rows.
-// The grid is 8 x 16: workgroup id % 8 is the XCD (profiles/r02_xcd_exchange_microbench.csv), so row tile r lives on XCD r
-// with its 16 column workgroups -- parties that share an L2 can publish with plain stores (0.4 us per exchange instead of
-// 1.2 us through memory).  The placement is CHECKED: the 16 workgroups of a row tile first exchange their XCC_ID with
-// agent-scope stores and fall back to release fences + agent-scope flags unless all ids agree.  Every wait is bounded; a
-// timeout raises a host-mapped flag that the next call reports (the handle then goes back to launches).
-// Same per-layer code (split_layer), same bits.
-// ------------------------------------------------------------------------------------------
-typedef unsigned long long u64;
-#ifdef VQCPC_RES_STAMPS
-__device__ unsigned long long g_res_stamps[64];
-#define RES_STAMP(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) g_res_stamps[(i)] = wall_clock64(); } while (0)
-extern "C" int vqcpc_debug_res_stamps(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_stamps), sizeof(g_res_stamps)) == hipSuccess ? 0 : -1;
-}
-#else
-#define RES_STAMP(i) do { } while (0)
-#endif
-struct ResidentP {
-    float *a, *b;               // raw rows, ping-pong: [N][512]
-    u64 *flags;                 // [8 row tiles][16 column groups][16]: one 128-B line per workgroup; [0] = layer tag, [1] = XCC_ID
-    unsigned *abort_flag;       // host-mapped
-};
-__global__ __launch_bounds__(256) void enc_resident_kernel(FusedP p, ResidentP rp) {
-    __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
-    __shared__ VqSmem sm;
-    __shared__ float part[2][16][17];
-    __shared__ int s_ok;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rt = blockIdx.x & 7, cg = blockIdx.x >> 3, r0 = rt * 16;
-    if (r0 >= p.N) return;
-    u64 *fl = rp.flags + (size_t)rt * 16 * 16;
-    // bounded sweep by wave 0 of the first `n` lines of this row tile until word `w` of each carries `want` in its high half;
-    // returns false (for the whole workgroup) on a timeout
-    auto sweep = [&](int n, int w, unsigned want, unsigned *low) -> bool {
-        if (wave == 0) {
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
-            bool ok = false;
-            u64 x = 0;
-            for (unsigned spins = 0;; ++spins) {
-                x = __hip_atomic_load(fl + (size_t)(lane < n ? lane : 0) * 16 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // tags only grow: a fast neighbour may already carry the next layer's
-                if (__all(w == 0 ? (unsigned)(x >> 32) >= want : (unsigned)(x >> 32) == want)) { ok = true; break; }
-                if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull ||
-                                           __hip_atomic_load(rp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!ok && lane == 0) __hip_atomic_store(rp.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (low) *low = (unsigned)x;
-            if (lane == 0) s_ok = ok ? 1 : 0;
-        }
-        __syncthreads();
-        const bool r = s_ok != 0;
-        __syncthreads();
-        return r;
-    };
-    // ---- are the 16 workgroups of this row tile on one XCD?
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xfu;
-    if (tid == 0) __hip_atomic_store(fl + (size_t)cg * 16 + 1, ((u64)0xC0DEu << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __shared__ int s_local;
-    {
-        unsigned other = 0;
-        if (!sweep(16, 1, 0xC0DEu, &other)) return;
-        if (wave == 0) { const bool same = __all(other == xcc); if (lane == 0) s_local = same ? 1 : 0; }
-        __syncthreads();
-    }
-    const bool local = s_local != 0;
-    RES_STAMP(0);
-    auto publish = [&](int tag) {
-        if (local) __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the slice is in this XCD's L2
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // ... or written back to memory
-        __syncthreads();
-        const u64 g = (u64)(unsigned)tag << 32;
-        if (tid == 0) {
-            if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(fl + (size_t)cg * 16), "v"(g) : "memory");
-            else __hip_atomic_store(fl + (size_t)cg * 16, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    RES_STAMP(1);
-    if (cg < 8) {                                        // conv: 8 column groups
-        split_conv(p, rp.a, cg, r0, tile);
-        RES_STAMP(3);
-        publish(1);
-        RES_STAMP(4);
-    }
-#pragma unroll 1                                         // ONE copy of the Linear body
-    for (int layer = 1; layer <= 4; ++layer) {
-        RES_STAMP(1 + 4 * layer);
-        if (!sweep(layer == 1 ? 8 : 16, 0, (unsigned)layer, nullptr)) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // L1 may hold this buffer's lines of two layers ago
-        RES_STAMP(2 + 4 * layer);
-        split_fc(p, layer, (layer & 1) ? rp.a : rp.b, (layer & 1) ? rp.b : rp.a, cg, r0, tile, part);
-        RES_STAMP(3 + 4 * layer);
-        publish(layer + 1);
-        RES_STAMP(4 + 4 * layer);
-    }
-    RES_STAMP(21);
-    if (!sweep(16, 0, 5u, nullptr)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    RES_STAMP(22);
-    if (cg != 0) return;
-    split_tail(p, rp.a, r0, tile, sm);
-    RES_STAMP(23);
-}
+// (A resident one-launch form of this schedule -- the 16 column workgroups of a row tile on one XCD, handing the rows over
+// in-kernel through that XCD's L2 -- was built and measured slower, 62 vs 50.5 us: profiles/r02_encoder_resident_timeline.txt.)
 
 // Eval-branch statistics of VQEmbeddingEMA.forward (model.py:147-153): deterministic two-level
 // reductions (per-block partials, then one block in fixed order).
@@ -1186,10 +1077,7 @@ struct vqcpc_encoder {
     float *codebook = nullptr, *e2 = nullptr, *cbfrag = nullptr;
     LstmPlan *lstm = nullptr;
     LnConst lnc;
-    DevBuf bufA, bufB, zpre, stats, resflags;
-    unsigned *abort_host = nullptr;      // pinned, host-mapped: a timed-out hand-off of the resident small-call kernel
-    bool res_pending = false;            // ... is reported by the next call
-    int resident = -1;                   // -1 auto (calls of up to 8 row tiles), 0 off
+    DevBuf bufA, bufB, zpre, stats;
     // fused front end (enc_fused_kernel): weights in 16x16x4 fragment order
     float4 *conv_f[2] = {nullptr, nullptr}, *fc_f[4] = {}, *out_f = nullptr;
     int fused = -1;                      // -1 auto (split below split_max_tiles row tiles, else fused), 0 layered kernels,
@@ -1211,8 +1099,6 @@ extern "C" void vqcpc_encoder_destroy(vqcpc_encoder *e) {
     for (int i = 0; i < 5; ++i) { if (e->ln_g[i]) (void)hipFree(e->ln_g[i]); if (e->ln_b[i]) (void)hipFree(e->ln_b[i]); }
     for (int i = 0; i < 4; ++i) if (e->fc_w[i]) (void)hipFree(e->fc_w[i]);
     if (e->lstm) vq_lstm_plan_destroy(e->lstm);
-    if (e->abort_host) (void)hipHostFree(e->abort_host);
-    e->resflags.release();
     float4 *fr[] = {e->conv_f[0], e->conv_f[1], e->fc_f[0], e->fc_f[1], e->fc_f[2], e->fc_f[3], e->out_f};
     for (float4 *q : fr) if (q) (void)hipFree(q);
     e->bufA.release(); e->bufB.release();
@@ -1253,8 +1139,7 @@ static int encoder_create_impl(const vqcpc_encoder_weights *w, vqcpc_encoder *e)
                        (float4 *)e->cbfrag, w->n_embeddings);
     HIP_TRY(hipGetLastError());
     TRY(vq_lstm_plan_create(w->rnn_w_ih, w->rnn_w_hh, w->rnn_b_ih, w->rnn_b_hh, w->z_dim, w->c_dim, &e->lstm));
-    HIP_TRY(hipHostMalloc((void **)&e->abort_host, 64, hipHostMallocMapped));
-    *e->abort_host = 0u;
+
     // fragment-ordered copies for the fused front end (the activation tile is 512 wide: 4 C <= 512)
     if (4 * C <= 512) {
         TRY(build_frag16(e->conv_w1, CH, 4 * C, &e->conv_f[0]));
@@ -1344,28 +1229,7 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
     p.eps = 1e-5f; p.lnc = e->lnc;
     const int ntiles = (N + 15) / 16;
     const bool split = stage < 0 && (e->fused == 2 || (e->fused != 1 && ntiles <= e->split_max_tiles));
-    if (e->res_pending) {                                 // did an earlier resident call report a timeout?  (host-mapped word)
-        e->res_pending = false;
-        if (*(volatile unsigned *)e->abort_host != 0u) {
-            *e->abort_host = 0u;
-            e->resident = 0;
-            vq_set_error("encoder: an in-kernel hand-off of the resident small-call kernel timed out; this handle now uses one "
-                         "launch per layer");
-            return VQCPC_ERR_HIP;
-        }
-    }
-    if (split && e->resident != 0 && ntiles <= 8 && e->abort_host) {     // a single utterance: the six layers in ONE resident launch
-        TRY(e->bufA.reserve((size_t)N * 512 * sizeof(float)));
-        TRY(e->bufB.reserve((size_t)N * 512 * sizeof(float)));
-        const size_t fb = (size_t)8 * 16 * 16 * sizeof(unsigned long long);
-        TRY(e->resflags.reserve(fb));
-        HIP_TRY(hipMemsetAsync(e->resflags.p, 0, fb, s));
-        ResidentP rp{};
-        rp.a = e->bufA.as<float>(); rp.b = e->bufB.as<float>(); rp.flags = e->resflags.as<unsigned long long>();
-        HIP_TRY(hipHostGetDevicePointer((void **)&rp.abort_flag, e->abort_host, 0));
-        hipLaunchKernelGGL(enc_resident_kernel, dim3(8 * 16), dim3(256), 0, s, p, rp);
-        e->res_pending = true;
-    } else if (split) {                                   // small call: six column-split launches (enc_split_kernel)
+    if (split) {                                          // small call: six column-split launches (enc_split_kernel)
         TRY(e->bufA.reserve((size_t)N * 512 * sizeof(float)));
         TRY(e->bufB.reserve((size_t)N * 512 * sizeof(float)));
         float *a = e->bufA.as<float>(), *b = e->bufB.as<float>();
@@ -1396,7 +1260,6 @@ extern "C" int vqcpc_encoder_set_option(vqcpc_encoder *e, const char *name, int 
         return VQCPC_OK;
     }
     if (!strcmp(name, "persistent_context")) return vq_lstm_set_persistent(e->lstm, value != 0 ? -1 : 0);
-    if (!strcmp(name, "resident")) { e->resident = value != 0 ? -1 : 0; return VQCPC_OK; }
     vq_set_error("unknown option %s", name);
     return VQCPC_ERR_INVALID;
 }
