@@ -851,7 +851,7 @@ __device__ __forceinline__ f32x4 rows16_gemm_pre(const float *tile, const float4
 }
 
 // The three layer kinds of the split schedule for column group `cg` of the row tile at r0 (bodies of enc_split_kernel):
-// conv (layer 0), Linear l = 1..4 (LayerNorm l-1 on load), encoder.14 + VQ (LayerNorm 4 on load).
+// conv (layer 0), Linear l = 1..4 (LayerNorm l-1 on load); encoder.14 + VQ (LayerNorm 4 on load) has a launch shape of its own.
 __device__ __forceinline__ void split_conv(const FusedP &p, float *__restrict__ out, int cg, int r0, float *tile) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K0 = 4 * p.C;
@@ -952,55 +952,69 @@ __device__ __forceinline__ void split_fc(const FusedP &p, int layer, const float
     }
 }
 
-__device__ __forceinline__ void split_tail(const FusedP &p, const float *__restrict__ in, int r0, float *tile, VqSmem &sm) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int layer = 5;
-    // this wave's weight slice first (it does not depend on anything), then the raw rows of the previous Linear / conv
-    // -> LDS, LayerNorm + ReLU in place
+// The last launch, one 512-thread workgroup per row tile: LayerNorm 4 + ReLU on load (a half-wave per row), encoder.14 with
+// its two K-block chains on wave pairs (as the fused launch's tail), VQ search on 8 waves.
+__global__ __launch_bounds__(512) void enc_split_tail_kernel(FusedP p, const float *__restrict__ in) {
+    __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
+    __shared__ VqSmem sm;
+    __shared__ float part[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.y * 16;
     // (vmcnt retires in order: the rows' loads go first, the weight slice behind them)
-    float4 av[8];
+    float4 av[4];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 512 * n, row = e >> 7, c4 = e & 127;
         av[n] = r0 + row < p.N ? ((const float4 *)in)[(size_t)(r0 + row) * 128 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 wf[32];
-    rows16_load_w<32>(p.out_f, wave, lane, wf);
+    const int ct = wave & 3, kh = wave >> 2;
+    float4 wh[16];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
+    for (int q = 0; q < 16; ++q) wh[q] = p.out_f[((size_t)ct * 32 + 16 * kh + q) * 64 + lane];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 512 * n, row = e >> 7, c4 = e & 127;
         float *d = tile + row * FE_LD + 4 * c4;
         *(float2 *)d = make_float2(av[n].x, av[n].y);
         *(float2 *)(d + 2) = make_float2(av[n].z, av[n].w);
     }
     __syncthreads();
-    rows16_layernorm<2>(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
+    rows16_layernorm<1>(tile, p.ln_g[4], p.ln_b[4], p.eps, p.lnc, tid);
     __syncthreads();
-    const int tpw = p.n_emb / 64, t0 = wave * tpw;
-    float4 f0[4], f1[4];
-    vq_load_tile(p.Ef, t0, lane, f0);
-    vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
-    const f32x4 zt = rows16_gemm_pre<2, 16>(tile, wf, wave, p.out_b, lane);
+    const int nwv = p.n_emb % 128 == 0 ? 8 : 4;          // waves of the VQ search
+    const int tpw = p.n_emb / (16 * nwv), t0 = (wave < nwv ? wave : 0) * tpw;
+    float4 f0[4] = {}, f1[4] = {};
+    if (wave < nwv) {
+        vq_load_tile(p.Ef, t0, lane, f0);
+        vq_load_tile(p.Ef, tpw > 1 ? t0 + 1 : t0, lane, f1);
+    }
+    // (bias + c0) + c1: wave w < 4 runs c0 of column tile w, wave w + 4 runs c1
+    const f32x4 zt = rows16_gemm_pre<1, 16>(tile + 256 * kh, wh, ct, kh == 0 ? p.out_b : nullptr, lane);
+    if (kh == 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
-        sm.xs[row][col] = zt[r];
-        if (p.z_pre && r0 + row < p.N) p.z_pre[(size_t)(r0 + row) * 64 + col] = zt[r];
+        for (int r = 0; r < 4; ++r) part[ct][4 * (lane >> 4) + r][lane & 15] = zt[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r, col = 16 * ct + (lane & 15);
+            const float z = zt[r] + part[ct][row][lane & 15];
+            sm.xs[row][col] = z;
+            if (p.z_pre && r0 + row < p.N) p.z_pre[(size_t)(r0 + row) * 64 + col] = z;
+        }
     }
     __syncthreads();
     if (tid < 16) sm.x2s[tid] = r0 + tid < p.N ? sumsq64(&sm.xs[tid][0]) : 0.f;
     __syncthreads();
-    vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1);
+    vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1, nwv);
 }
 
 __global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, const float *__restrict__ in, float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
-    __shared__ VqSmem sm;
     __shared__ float part[2][16][17];
     const int cg = blockIdx.x, r0 = blockIdx.y * 16;
     if (layer == 0) split_conv(p, out, cg, r0, tile);
-    else if (layer < 5) split_fc(p, layer, in, out, cg, r0, tile, part);
-    else split_tail(p, in, r0, tile, sm);
+    else split_fc(p, layer, in, out, cg, r0, tile, part);
 }
 
 // (A resident one-launch form of this schedule -- the 16 column workgroups of a row tile on one XCD, handing the rows over
@@ -1238,7 +1252,7 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
             hipLaunchKernelGGL(enc_split_kernel, dim3(16, ntiles), dim3(256), 0, s, p, l, (const float *)a, b);
             float *t = a; a = b; b = t;
         }
-        hipLaunchKernelGGL(enc_split_kernel, dim3(1, ntiles), dim3(256), 0, s, p, 5, (const float *)a, (float *)nullptr);
+        hipLaunchKernelGGL(enc_split_tail_kernel, dim3(1, ntiles), dim3(512), 0, s, p, (const float *)a);
     } else {
         hipLaunchKernelGGL(enc_fused_kernel, dim3(ntiles), dim3(512), 0, s, p);
     }
