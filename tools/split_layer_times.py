@@ -11,7 +11,7 @@ rows = []
 for path in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            if "enc_split_kernel" in r["Kernel_Name"]:
+            if "enc_split_" in r["Kernel_Name"]:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)))
 rows.sort()
 acc = defaultdict(list)

@@ -850,7 +850,7 @@ __device__ __forceinline__ f32x4 rows16_gemm_pre(const float *tile, const float4
     return tot;
 }
 
-// The three layer kinds of the split schedule for column group `cg` of the row tile at r0 (bodies of enc_split_kernel):
+// The three layer kinds of the split schedule for column group `cg` of the row tile at r0 (bodies of the enc_split_*_kernel launches):
 // conv (layer 0), Linear l = 1..4 (LayerNorm l-1 on load); encoder.14 + VQ (LayerNorm 4 on load) has a launch shape of its own.
 __device__ __forceinline__ void split_conv(const FusedP &p, float *__restrict__ out, int cg, int r0, float *tile) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -909,45 +909,44 @@ __device__ __forceinline__ void split_conv(const FusedP &p, float *__restrict__ 
     }
 }
 
+// 512 threads: 8 column groups per row tile; a workgroup = 4 column tiles x the 2 K halves of the chain fold (they are
+// independent zero-started chains: tot = c0 + c1), so a wave streams 16 KB of weights and issues 64 MFMAs; every column
+// workgroup repeats the LayerNorm of its row tile, a half-wave per row.
 __device__ __forceinline__ void split_fc(const FusedP &p, int layer, const float *__restrict__ in, float *__restrict__ out, int cg,
                                          int r0, float *tile, float (*part)[16][17]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // this wave's weight slice first (it does not depend on anything), then the raw rows of the previous Linear / conv
-    // -> LDS, LayerNorm + ReLU in place
     // (vmcnt retires in order: the rows' loads go first, the weight slice behind them)
-    float4 av[8];
+    float4 av[4];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 512 * n, row = e >> 7, c4 = e & 127;
         av[n] = r0 + row < p.N ? ((const float4 *)in)[(size_t)(r0 + row) * 128 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // Linear l: 16 column groups per row tile; a workgroup = 2 column tiles x the 2 K halves of the chain fold (they are
-    // independent zero-started chains: tot = c0 + c1), so a wave streams 16 KB of weights and issues 64 MFMAs
-    const int ct = 2 * cg + (wave & 1), kh = wave >> 1;
+    const int cl = wave & 3, ct = 4 * cg + cl, kh = wave >> 2;
     float4 wh[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) wh[q] = p.fc_f[layer - 1][((size_t)ct * 32 + 16 * kh + q) * 64 + lane];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const int e = tid + 256 * n, row = e >> 7, c4 = e & 127;
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 512 * n, row = e >> 7, c4 = e & 127;
         float *d = tile + row * FE_LD + 4 * c4;
         *(float2 *)d = make_float2(av[n].x, av[n].y);
         *(float2 *)(d + 2) = make_float2(av[n].z, av[n].w);
     }
     __syncthreads();
-    rows16_layernorm<2>(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
+    rows16_layernorm<1>(tile, p.ln_g[layer - 1], p.ln_b[layer - 1], p.eps, p.lnc, tid);
     __syncthreads();
     const f32x4 acc = rows16_gemm_pre<1, 16>(tile + 256 * kh, wh, ct, nullptr, lane);      // k in [256 kh, 256 kh + 256)
     if (kh == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[wave & 1][4 * (lane >> 4) + r][lane & 15] = acc[r];
+        for (int r = 0; r < 4; ++r) part[cl][4 * (lane >> 4) + r][lane & 15] = acc[r];
     }
     __syncthreads();
     if (kh == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = r0 + 4 * (lane >> 4) + r;
-            if (m < p.N) out[(size_t)m * 512 + 16 * ct + (lane & 15)] = acc[r] + part[wave & 1][4 * (lane >> 4) + r][lane & 15];
+            if (m < p.N) out[(size_t)m * 512 + 16 * ct + (lane & 15)] = acc[r] + part[cl][4 * (lane >> 4) + r][lane & 15];
         }
     }
 }
@@ -1009,12 +1008,14 @@ __global__ __launch_bounds__(512) void enc_split_tail_kernel(FusedP p, const flo
     vq_rows16(sm, r0, p.N, p.Ef, p.E, p.e2, p.n_emb, p.idx, p.z_q, tid, f0, f1, nwv);
 }
 
-__global__ __launch_bounds__(256) void enc_split_kernel(FusedP p, int layer, const float *__restrict__ in, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void enc_split_conv_kernel(FusedP p, float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
-    __shared__ float part[2][16][17];
-    const int cg = blockIdx.x, r0 = blockIdx.y * 16;
-    if (layer == 0) split_conv(p, out, cg, r0, tile);
-    else split_fc(p, layer, in, out, cg, r0, tile, part);
+    split_conv(p, out, blockIdx.x, blockIdx.y * 16, tile);
+}
+__global__ __launch_bounds__(512) void enc_split_fc_kernel(FusedP p, int layer, const float *__restrict__ in, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
+    __shared__ float part[4][16][17];
+    split_fc(p, layer, in, out, blockIdx.x, blockIdx.y * 16, tile, part);
 }
 
 // (A resident one-launch form of this schedule -- the 16 column workgroups of a row tile on one XCD, handing the rows over
@@ -1243,13 +1244,13 @@ static int encoder_fused(vqcpc_encoder *e, const float *mel, int B, int T, int c
     p.eps = 1e-5f; p.lnc = e->lnc;
     const int ntiles = (N + 15) / 16;
     const bool split = stage < 0 && (e->fused == 2 || (e->fused != 1 && ntiles <= e->split_max_tiles));
-    if (split) {                                          // small call: six column-split launches (enc_split_kernel)
+    if (split) {                                          // small call: six column-split launches (enc_split_*_kernel)
         TRY(e->bufA.reserve((size_t)N * 512 * sizeof(float)));
         TRY(e->bufB.reserve((size_t)N * 512 * sizeof(float)));
         float *a = e->bufA.as<float>(), *b = e->bufB.as<float>();
-        hipLaunchKernelGGL(enc_split_kernel, dim3(8, ntiles), dim3(256), 0, s, p, 0, (const float *)nullptr, a);
+        hipLaunchKernelGGL(enc_split_conv_kernel, dim3(8, ntiles), dim3(256), 0, s, p, a);
         for (int l = 1; l <= 4; ++l) {
-            hipLaunchKernelGGL(enc_split_kernel, dim3(16, ntiles), dim3(256), 0, s, p, l, (const float *)a, b);
+            hipLaunchKernelGGL(enc_split_fc_kernel, dim3(8, ntiles), dim3(512), 0, s, p, l, (const float *)a, b);
             float *t = a; a = b; b = t;
         }
         hipLaunchKernelGGL(enc_split_tail_kernel, dim3(1, ntiles), dim3(512), 0, s, p, (const float *)a);
