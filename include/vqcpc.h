@@ -103,7 +103,7 @@ int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int
  * LayerNorms + FC stack + VQ search for 16 whole rows per workgroup with the activations resident in LDS; 2 = six
  * column-split launches (one per Linear, LayerNorm applied on load, VQ in the last) for calls too small to fill the chip
  * with whole-row workgroups; 0 = the layered kernels, one launch per module of model.py:43-55; -1 (default) = 2 for calls
- * of up to `split_max_tiles` (default 64) 16-row tiles, else 1; 0 when 4 * in_channels > 512.
+ * of up to `split_max_tiles` (default 80) 16-row tiles, else 1; 0 when 4 * in_channels > 512.
  * persistent_context (default 1): the context LSTM (model.py:57) of a ONE-utterance call -- encode.py:42-46's batch 1 --
  * runs as one resident kernel with in-kernel exchanges of h_t instead of one launch per time step; 0 = always launches.
  * Same bits either way. */

@@ -184,7 +184,7 @@ def test_full_size_properties():
 def test_layered_and_fused_front_ends_same_bits(name, golden_dir):
     """The one-launch fused front end (1), the six column-split launches for small calls (2) and the layered kernels
     (0, one launch per module) are three schedules of the same rounding sequence: every stage, z, z_pre and the indices
-    carry the same bits, and they equal the reference's SHAs.  (Default: 2 up to 64 row tiles, else 1.)"""
+    carry the same bits, and they equal the reference's SHAs.  (Default: 2 up to 80 row tiles, else 1.)"""
     g, enc, sd, mel = load_case(name, golden_dir)
     melc = mel.cuda()
     outs = {}

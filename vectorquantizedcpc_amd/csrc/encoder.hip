@@ -1097,7 +1097,7 @@ struct vqcpc_encoder {
     float4 *conv_f[2] = {nullptr, nullptr}, *fc_f[4] = {}, *out_f = nullptr;
     int fused = -1;                      // -1 auto (split below split_max_tiles row tiles, else fused), 0 layered kernels,
                                          // 1 one-launch fused kernel, 2 six-launch column-split kernels
-    int split_max_tiles = 64;            // auto: calls of up to this many 16-row tiles take the column-split launches
+    int split_max_tiles = 80;            // auto: calls of up to this many 16-row tiles take the column-split launches
 };
 
 static int dev_copy(float **dst, const float *src, size_t n) {
