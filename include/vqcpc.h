@@ -105,7 +105,8 @@ int vqcpc_encoder_encode(vqcpc_encoder *enc, const float *mel, int B, int T, int
  * with whole-row workgroups; 0 = the layered kernels, one launch per module of model.py:43-55; -1 (default) = 2 for calls
  * of up to `split_max_tiles` (default 80) 16-row tiles, else 1; 0 when 4 * in_channels > 512.
  * persistent_context (default 1): the context LSTM (model.py:57) of a ONE-utterance call -- encode.py:42-46's batch 1 --
- * runs as one resident kernel with in-kernel exchanges of h_t instead of one launch per time step; 0 = always launches.
+ * runs as one resident kernel with in-kernel exchanges of h_t instead of one launch per time step; 0 = always launches;
+ * 2 = the resident kernel with agent-scope stores forced (its fallback when the workers do not share an XCD; for tests).
  * Same bits either way. */
 int vqcpc_encoder_set_option(vqcpc_encoder *enc, const char *name, int value);
 

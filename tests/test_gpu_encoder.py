@@ -111,13 +111,15 @@ def test_single_utterance_context_resident_scan_same_bits():
         melc = mel.cuda()
         _, c_res, _ = enc.encode(melc)
         _, c_res2, _ = enc.encode(melc)
-        enc.set_option("persistent_context", 0)
         try:
+            enc.set_option("persistent_context", 2)      # the fallback: agent-scope stores (workers not on one XCD)
+            _, c_agent, _ = enc.encode(melc)
+            enc.set_option("persistent_context", 0)
             _, c_steps, _ = enc.encode(melc)
         finally:
             enc.set_option("persistent_context", 1)
         assert c_res.shape == (1, T // 2, 256)
-        assert torch.equal(c_res, c_steps) and torch.equal(c_res, c_res2), T
+        assert torch.equal(c_res, c_steps) and torch.equal(c_res, c_res2) and torch.equal(c_res, c_agent), T
         want = oracle.encoder_encode(sd, mel.numpy())["c"]
         assert np.abs(c_res.cpu().numpy() - want).max() <= 1e-6, T
 

@@ -1274,7 +1274,7 @@ extern "C" int vqcpc_encoder_set_option(vqcpc_encoder *e, const char *name, int 
         e->split_max_tiles = value;
         return VQCPC_OK;
     }
-    if (!strcmp(name, "persistent_context")) return vq_lstm_set_persistent(e->lstm, value != 0 ? -1 : 0);
+    if (!strcmp(name, "persistent_context")) return vq_lstm_set_persistent(e->lstm, value == 2 ? 2 : (value != 0 ? -1 : 0));
     vq_set_error("unknown option %s", name);
     return VQCPC_ERR_INVALID;
 }

@@ -232,7 +232,7 @@ struct LstmPlan {
     float *w_hh = nullptr;               // plain [4H][H] copy for the persistent single-utterance scan
     DevBuf gi, hbuf, cbuf, px;
     unsigned *abort_host = nullptr;      // pinned, host-mapped: a timed-out exchange of the persistent scan is reported by the next call
-    int persistent = -1;                 // -1 auto (one utterance, H = 256), 0 off
+    int persistent = -1;                 // -1 auto (one utterance, H = 256), 0 off, 2 = auto with agent-scope stores forced (tests)
     bool pending = false;                // a persistent scan may have raised the flag
 };
 static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s);
@@ -1211,6 +1211,7 @@ struct LstmPersistP {
                           // publishes h_t while a slow one still sweeps h_{t-1}; it cannot reach h_{t+1} before that sweep ended
     unsigned *abort_flag;
     int T;
+    int force_agent;      // tests: publish with agent-scope stores even when all workers share an XCD (the fallback path)
 };
 template <bool LOCAL>
 __device__ __forceinline__ void lp_store(u64 *p, u64 v) {
@@ -1240,7 +1241,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistP p) {
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 0;; ++spins) {
             const u64 x = ps_load(p.g + (size_t)(lane & 31) * PS_PAD + 8);
-            if (__all((unsigned)(x >> 32) == 0xC0DEu)) { local = __all((unsigned)x == xcc); break; }
+            if (__all((unsigned)(x >> 32) == 0xC0DEu)) { local = __all((unsigned)x == xcc) && !p.force_agent; break; }
             if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
                                        __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
                 if (lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1287,6 +1288,7 @@ static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(p->px.p, 0, bytes, s));
     LstmPersistP q{};
     q.w_hh = p->w_hh; q.Gi = p->gi.as<float>(); q.out = out; q.g = p->px.as<u64>(); q.T = T;
+    q.force_agent = p->persistent == 2;
     HIP_TRY(hipHostGetDevicePointer((void **)&q.abort_flag, p->abort_host, 0));
     hipLaunchKernelGGL(lstm_persist_kernel, dim3(8 * LP_NW), dim3(256), 0, s, q);
     HIP_TRY(hipGetLastError());
