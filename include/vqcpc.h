@@ -133,6 +133,15 @@ int vqcpc_encoder_forward_stats(vqcpc_encoder *enc, const float *z_pre, const fl
                                 const int64_t *idx, int n_rows, float *z_st, float *loss,
                                 float *perplexity, void *stream);
 
+/* After the caller has synchronised the stream that carried vqcpc_encoder_encode / _context: did the resident context
+ * scan of that call (persistent_context) give up on an in-kernel exchange?  VQCPC_OK, or VQCPC_ERR_HIP: the context `c`
+ * of that call is incomplete, the handle now runs one launch per time step, and the call should be repeated.  Reads a
+ * host-mapped word: no HIP call, no synchronisation.  The reference has no counterpart (its operators are synchronous,
+ * encode.py:45-46): consumers that read results back -- driver.encode_utterances, cli.encode_dataset -- call it
+ * before anything is written.  Options for tests of this path: context_debug_drop_step (one worker skips its publish at
+ * that time step), context_timeout_ms. */
+int vqcpc_encoder_check(vqcpc_encoder *enc);
+
 /* nn.LSTM over z (B, Tz, z_dim) -> c (B, Tz, c_dim)  (model.py:69 / :85). */
 int vqcpc_encoder_context(vqcpc_encoder *enc, const float *z, int B, int Tz, float *c,
                           void *stream);
@@ -207,6 +216,13 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * fuse_fc1 (default 0, needs fuse_fc2): fc1 of sample t-1 rides in the same launch as well -- it reads the state the
  * previous launch wrote and hands its outputs to the fc2 teams as granules: ONE launch per sample.  Same bits, but
  * measured slower than two launches at every batch size (the hand-off is 32 KB per fc2 team), so it is off.
+ * xcd (default -1 = auto, 0 never, 1 whenever the dimensions are the reference's): generate() runs as EIGHT resident,
+ * weight-stationary decoders, one per XCD (ar_xcd.hip): decode slot s lives on XCD s % 8; each XCD keeps a full copy of the
+ * recurrent weights on its 32 CUs (W_hh in VGPRs, fc1 / fc2 / the sample-embedding table in LDS) and exchanges h_t, a_t and
+ * the draw candidates through its own L2; no launches per sample.  Same samples as every other path.  xcd_slots: decode
+ * slots it may use (default and maximum 32); more utterances than slots run back to back in them (longest first).
+ * xcd_agent_stores / xcd_timeout_ms / xcd_debug_drop_step, handoff_timeout_ms / handoff_debug_drop_step: A-B and tests
+ * of the abort path (one worker skips a publish at that step; the waits give up after the timeout; vqcpc_vocoder_check).
  * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
  * use_graph: replay the per-sample kernels from a captured hipGraph
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
@@ -215,6 +231,15 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * large-batch GRU kernel is used (default 5, 0 = never).  two_groups: run calls of 3..big_min_tiles-1
  * tiles, or of >= 2*big_min_tiles tiles, as two independent tile groups on two streams (default 1). */
 int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
+
+/* After the caller has synchronised the stream that carried vqcpc_vocoder_generate: did an in-kernel hand-off of that
+ * call (per-XCD decoders, persistent decoder, fused fc2 || GRU launch) time out, or were the per-XCD decoder's workgroups
+ * not dealt 32 to each XCD?  VQCPC_OK, or VQCPC_ERR_HIP: the waveform of that call is incomplete (or was not written at
+ * all), the handle has fallen back to one launch per kernel and step, and the call should be repeated -- the repeat
+ * gives the same samples the fast path would have (the sampling stream does not depend on the path).  Reads a
+ * host-mapped word: no HIP call.  convert.py:75-83 writes the wav right after generate(): driver.convert_utterances,
+ * cli.convert and shard.convert_sharded call this before anything is written or gathered. */
+int vqcpc_vocoder_check(vqcpc_vocoder *voc);
 
 /* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call
  * (HIP events on the launch stream) and the number of samples per utterance it covers.

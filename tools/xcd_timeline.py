@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Where one sample step of the per-XCD resident decoder (csrc/ar_xcd.hip) goes: wall-clock stamps (10 ns ticks) of
+worker 5 of XCD 0 over steps 256..383.
+
+Needs the debug build (stamps are compiled out of the shipped library):
+    mkdir -p build/stamps && for f in encoder vocoder ar_xcd melfront loudness resample; do /opt/rocm/bin/hipcc -O3 -std=c++17 \
+        -fPIC --offload-arch=gfx950 -ffp-contract=off -DVQCPC_XD_STAMPS -c vectorquantizedcpc_amd/csrc/$f.hip -o build/stamps/$f.o; done
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/stamps/libvqcpc_hip.so build/stamps/*.o
+    python3 tools/xcd_timeline.py [utterances ...]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vectorquantizedcpc_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "build", "stamps", "libvqcpc_hip.so")
+import vectorquantizedcpc_amd as V  # noqa: E402
+from vectorquantizedcpc_amd import synth  # noqa: E402
+
+voc = V.Vocoder(V.ConfVocoder())
+voc.load_state_dict(synth.vocoder_state_dict())
+voc = voc.cuda().eval()
+voc.set_option("xcd", 1)
+for B in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 32]:
+    z = synth.randint("timeline", (B, 4), 512).cuda()
+    spk = torch.zeros(B, dtype=torch.long, device="cuda")
+    voc.generate(z, spk, seed=13)
+    voc.check()
+    ms, n = voc.last_timing()
+    buf = (C.c_ulonglong * (128 * 16))()
+    assert _lib.load().vqcpc_debug_xd_stamps(buf) == 0
+    s = np.array(buf, dtype=np.int64).reshape(128, 16) * 0.01     # us
+    a, b = s[4:120], s[5:121]
+    rows = [
+        ("wave 11: step entry -> x_{t-1} known (candidate sweep + argmax)", a[:, 1] - a[:, 0]),
+        ("wave 11: previous barrier B -> step entry", a[:, 0] - s[3:119, 12]),
+        ("wave 11: x known -> own h_t published (cell update)", a[:, 2] - a[:, 1]),
+        ("wave 11: h published -> h_t of all 32 workers gathered", a[:, 3] - a[:, 2]),
+        ("barrier A", a[:, 4] - a[:, 3]),
+        ("wave 11: barrier A -> fc1 rows of its slots published", a[:, 5] - a[:, 4]),
+        ("wave 10: barrier A -> fc1 rows of its slots published", a[:, 10] - a[:, 4]),
+        ("wave 10: then W_hh rows 80..83, all slots", a[:, 11] - a[:, 10]),
+        ("wave 0: barrier A -> W_hh h_t chains done, all slots", a[:, 6] - a[:, 4]),
+        ("wave 11: fc1 published -> W_hh rows 80..83 of its slots done", a[:, 7] - a[:, 5]),
+        ("wave 11: then -> a_t gathered", a[:, 8] - a[:, 7]),
+        ("wave 11: a_t gathered -> candidates published (fc2 + draw)", a[:, 9] - a[:, 8]),
+        ("candidates published -> past barrier B", a[:, 12] - a[:, 9]),
+        ("whole step", b[:, 0] - a[:, 0]),
+    ]
+    print(f"per-XCD decoders, {B} utterance(s): {ms * 1e3 / n:.2f} us per sample step over the call; worker 5 of XCD 0, "
+          f"mean / min / max over 116 steps, us")
+    for name, d in rows:
+        print(f"  {name:66s} {d.mean():6.2f} {d.min():6.2f} {d.max():6.2f}")

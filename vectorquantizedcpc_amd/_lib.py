@@ -14,6 +14,7 @@ SYMBOLS = [
     "vqcpc_abi_version", "vqcpc_last_error", "vqcpc_device_count",
     "vqcpc_encoder_create", "vqcpc_encoder_destroy", "vqcpc_encoder_encode",
     "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage", "vqcpc_encoder_vq_encode", "vqcpc_encoder_set_option",
+    "vqcpc_encoder_check", "vqcpc_vocoder_check",
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
@@ -71,6 +72,8 @@ def load():
     lib.vqcpc_encoder_stage.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.vqcpc_encoder_vq_encode.argtypes = [vp, vp, i32, vp, i64p, vp]
     lib.vqcpc_encoder_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.vqcpc_encoder_check.argtypes = [vp]
+    lib.vqcpc_vocoder_check.argtypes = [vp]
     lib.vqcpc_vocoder_create.argtypes = [C.POINTER(VocoderWeights), C.POINTER(vp)]
     lib.vqcpc_vocoder_destroy.argtypes = [vp]
     lib.vqcpc_vocoder_destroy.restype = None
@@ -120,20 +123,34 @@ class WeightSlots:
 
     def __init__(self, module, names):
         self.names = list(names)
-        self.slots = []
+        self.module = module
+        self._resolve()
+
+    def _resolve(self):
+        self.slots, self.owners = [], []
         for name in self.names:
             *path, leaf = name.split(".")
-            mod = module
+            mod, chain = self.module, []
             for part in path:
+                chain.append((mod._modules, part, mod._modules[part]))
                 mod = mod._modules[part]
             self.slots.append((mod._parameters if leaf in mod._parameters else mod._buffers, leaf))
+            self.owners.append(chain)
 
     def tensors(self):
+        # a submodule replaced after the first call (enc.rnn = nn.LSTM(...)) leaves the resolved dicts pointing at the old
+        # one: one identity check per path element (~1 us for the whole list) catches it
+        for chain in self.owners:
+            for mods, part, seen in chain:
+                if mods.get(part) is not seen:
+                    self._resolve()
+                    return [d[k] for d, k in self.slots]
         return [d[k] for d, k in self.slots]
 
     @staticmethod
     def key(tensors):
-        return tuple([(t.data_ptr(), t._version) for t in tensors])
+        dev = tensors[0].device
+        return (dev.type, dev.index) + tuple([(t.data_ptr(), t._version) for t in tensors])
 
 
 def device_guard(dev):

@@ -49,6 +49,12 @@ def encode_dataset(args) -> int:
         # the hook delivers one batch at a time: keep the reference's one-utterance-per-call order
         for p, mel in zip(paths, mels):
             z, c, _ = enc.encode(mel[None].to(args.device))
+            try:
+                enc.check()                                    # nothing incomplete may be written
+            except RuntimeError:
+                aux.clear()
+                z, c, _ = enc.encode(mel[None].to(args.device))
+                enc.check()
             io.save_frames_text(out_dir / p.stem, z[0])
             for name, t in (("auxiliary_embedding1", c[0]), ("auxiliary_embedding2", aux.pop()[0])):
                 d = out_dir.parent / name

@@ -1,0 +1,676 @@
+// ar_xcd.hip -- the WaveRNN-style sample loop of Vocoder.generate (network_vocoder.py:78; RNN_MS spec: DESIGN.md 2.2) as
+// EIGHT independent, weight-stationary, resident decoders: one per XCD.
+//
+// Utterances are independent, so they are dealt over the 8 XCDs (decode slot s lives on XCD s % 8) and each XCD runs its
+// own copy of the recurrence on its 32 CUs, with a full copy of the weights held ON the CUs for the whole call:
+//   * workgroup `rank` (0..31, one per CU, 768 threads) owns hidden units 28 rank .. 28 rank + 27 = 84 gate rows of W_hh
+//     (80 of them in VGPRs, 112 weights per lane = one fp32 fma chain of the row; the last 4 in LDS), 8 rows of fc1 and
+//     8 classes of fc2 (36.9 KB, LDS) and its slice of the sample-embedding table Gemb (86 KB, LDS);
+//   * nothing is re-fetched per sample: after the prologue the only global traffic is the three all-to-all exchanges of a
+//     sample step (h_t, a_t, the draw candidates) as 8-byte {tag, value} granules (the data is the flag), which stay
+//     inside the XCD: published with workgroup-scope stores (the write-through L1 leaves them in the XCD's L2) and swept
+//     with sc1 loads that bypass L1 -- 0.41 us per exchange against 1.2 us across XCDs
+//     (profiles/r02_xcd_exchange_microbench.csv).  The placement is CHECKED, not assumed: every workgroup reads its
+//     XCC_ID and takes a ticket; unless each XCD got exactly 32 workgroups the launch gives up (status 2) before it
+//     touches any output, and the host falls back to the launch-per-step kernels.
+// Arithmetic is bit-identical to those kernels: a row's dot product is the same 8 fp32 fma chains (K quarter x x/z|y/w
+// accumulator: ar_shared.h), combined in the same order; cell update, fc epilogues and the Gumbel-max draw are the
+// same expressions.  A chain lives in ONE lane; the four lanes of a quad hold the same chain of four different rows and
+// share its operand values (each lane loads a quarter of h from LDS, v_fmac_f32_dpp quad_perm broadcasts them), which
+// cuts the LDS operand traffic by 4 and leaves the step VALU-bound.
+//
+// Roles of the 12 waves of a workgroup:
+//   waves 0..9   W_hh h_t chains of rows 0..79 for every slot of the XCD (8 rows per wave, weights pinned in VGPRs) -> gsum
+//   wave 11 / 10 everything that is serial in a sample step, for the even / odd slots: x_{t-1} from the slot's 32
+//                candidates; cell update of the 28 owned units; publish h_t; the draw's noise; fc1 (weights re-read
+//                from LDS every step) -> publish a_t; sweep of a_t; fc2 + Gumbel-max candidate -> publish; and, in the
+//                shadows of the a_t and the candidate exchanges, W_hh rows 80..83 for the OTHER wave's slots
+//   all waves    sweep h_t into LDS
+// Two workgroup barriers per sample.  Every wait is wall-clock bounded; a timeout sets status bit 0, every workgroup
+// leaves, and the call's outputs are incomplete (vqcpc_vocoder_check reports it).
+#include "ar_xcd.h"
+#include "ar_shared.h"
+
+// Timeline stamps of worker 5 of XCD 0 (100 MHz wall clock), steps 256..383, for tools/xcd_timeline.py: compiled in only
+// with -DVQCPC_XD_STAMPS (a debug build under build/stamps/, never the shipped library).
+#ifdef VQCPC_XD_STAMPS
+__device__ unsigned long long g_xd_stamps[128 * 16];
+#define XD_STAMP(wv, i) do { if (rank == 5 && xcc == 0 && wave == (wv) && lane == 0 && t >= 256 && t < 384) \
+        g_xd_stamps[(t - 256) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int vqcpc_debug_xd_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xd_stamps), sizeof(g_xd_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define XD_STAMP(wv, i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int HR = 896, HF = 256, NC = 256;
+constexpr int NW = 32;                 // workgroups per XCD
+constexpr int UPB = 28;                // hidden units per workgroup
+constexpr int ROWS = 3 * UPB;          // W_hh rows per workgroup
+constexpr int FPB = 8;                 // fc1 rows / fc2 classes per workgroup
+constexpr int THREADS = 768;
+constexpr int NT_H = HR / 8;           // terms of a chain over h: 112
+constexpr int NT_A = HF / 8;           // terms of a chain over a: 32
+
+// exchange area of one XCD, in granules
+__host__ __device__ constexpr int xg_h(int bxt) { return NW * bxt * 32; }         // [rank][slot][32] (28 used: two whole lines)
+__host__ __device__ constexpr int xg_a(int bxt) { return NW * bxt * FPB; }        // [rank][slot][8]
+__host__ __device__ constexpr int xg_c() { return NW * 16; }                      // [rank][16] (one line per rank)
+__host__ __device__ constexpr int xg_region(int bxt) { return xg_h(bxt) + xg_a(bxt) + xg_c(); }
+constexpr int CTL_WORDS = 64;          // u32: arrivals per XCC [0..7], total [8]
+
+
+
+// Granule traffic is addressed as (uniform 64-bit base in SGPRs) + (32-bit byte offset in a VGPR) + immediate: a 64-bit
+// address per lane and granule costs two VGPRs each, and the chain waves have none to spare.  The loads are sc1 (served by
+// L2, not by this CU's L1); each helper issues its loads together and returns when they have landed (hipcc does not count
+// the memory operations of an asm statement, so the wait is part of it; nor does it pad the hazard between a VALU write of
+// the base SGPRs (v_readfirstlane) and a vector-memory instruction inside the statement reading them: every statement
+// opens with the five wait states itself -- without them the stamped build and the 2-slot instantiation faulted).
+__device__ __forceinline__ void xd_put(u64 *base, unsigned byte_off, u64 v, int agent) {
+    if (agent) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" :: "v"(byte_off), "v"(v), "s"(base) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc0" :: "v"(byte_off), "v"(v), "s"(base) : "memory");   // stays in this XCD's L2
+}
+template <int STEP>
+__device__ __forceinline__ void gran_load1(u64 (&v)[1], const u64 *base, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(off), "s"(base) : "memory");
+}
+template <int STEP>
+__device__ __forceinline__ void gran_load2(u64 (&v)[2], const u64 *base, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3 sc1\n\tglobal_load_dwordx2 %1, %2, %3 offset:%4 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(off), "s"(base), "i"(STEP) : "memory");
+}
+template <int STEP>
+__device__ __forceinline__ void gran_load4(u64 (&v)[4], const u64 *base, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5 sc1\n\tglobal_load_dwordx2 %1, %4, %5 offset:%6 sc1\n\t"
+                 "global_load_dwordx2 %2, %4, %5 offset:%7 sc1\n\tglobal_load_dwordx2 %3, %4, %5 offset:%8 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(base), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP) : "memory");
+}
+template <int STEP>     // granules at off, off + STEP (from base) and the same two from base2
+__device__ __forceinline__ void gran_load4b(u64 (&v)[4], const u64 *base, const u64 *base2, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5 sc1\n\tglobal_load_dwordx2 %1, %4, %5 offset:%7 sc1\n\t"
+                 "global_load_dwordx2 %2, %4, %6 sc1\n\tglobal_load_dwordx2 %3, %4, %6 offset:%7 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(base), "s"(base2), "i"(STEP) : "memory");
+}
+template <int N, int STEP>
+__device__ __forceinline__ void gran_load(u64 (&v)[N], const u64 *base, unsigned off) {
+    if constexpr (N == 1) gran_load1<STEP>(v, base, off);
+    if constexpr (N == 2) gran_load2<STEP>(v, base, off);
+    if constexpr (N == 4) gran_load4<STEP>(v, base, off);
+}
+
+// acc += (value of `h` in lane J of this lane's quad) * w -- one fp32 fma, as the MFMA chain does it.  Eight (four)
+// consecutive terms of a chain go into ONE asm statement: hipcc pads every asm statement with an s_nop, which at one
+// fmac per statement doubled the instruction count of a chain (13 cycles per term measured; the terms of one statement
+// need no padding among themselves: the accumulator is an ordinary operand, the DPP operand comes from LDS loads).
+#define XD_QP(J) "quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
+#define XD_FMAC8(J)                                                                                                      \
+    asm("v_fmac_f32_dpp %0, %1, %9 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %2, %10 " XD_QP(J) "\n\t"                        \
+        "v_fmac_f32_dpp %0, %3, %11 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %4, %12 " XD_QP(J) "\n\t"                       \
+        "v_fmac_f32_dpp %0, %5, %13 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %6, %14 " XD_QP(J) "\n\t"                       \
+        "v_fmac_f32_dpp %0, %7, %15 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %8, %16 " XD_QP(J)                              \
+        : "+v"(acc)                                                                                                      \
+        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(h[4]), "v"(h[5]), "v"(h[6]), "v"(h[7]),                       \
+          "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]))
+#define XD_FMAC4(J)                                                                                                      \
+    asm("v_fmac_f32_dpp %0, %1, %5 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %2, %6 " XD_QP(J) "\n\t"                         \
+        "v_fmac_f32_dpp %0, %3, %7 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %4, %8 " XD_QP(J)                                \
+        : "+v"(acc)                                                                                                      \
+        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]))
+// terms 8 J .. 8 J + 7 of a 32-term phase: operands h[0..7] as held by quad lane J, weights w[0..7]
+template <int J>
+__device__ __forceinline__ void fmac8(float &acc, const float *h, const float *w) {
+    if constexpr (J == 0) XD_FMAC8(0);
+    if constexpr (J == 1) XD_FMAC8(1);
+    if constexpr (J == 2) XD_FMAC8(2);
+    if constexpr (J == 3) XD_FMAC8(3);
+}
+template <int J>
+__device__ __forceinline__ void fmac4(float &acc, const float *h, const float *w) {
+    if constexpr (J == 0) XD_FMAC4(0);
+    if constexpr (J == 1) XD_FMAC4(1);
+    if constexpr (J == 2) XD_FMAC4(2);
+    if constexpr (J == 3) XD_FMAC4(3);
+}
+// one phase: len = 32 (8 terms per quad lane) or 16 (4 per lane); w = the phase's weights in term order
+template <int LEN>
+__device__ __forceinline__ void chain_phase(float &acc, const float (&hv)[8], const float *w) {
+    if constexpr (LEN == 32) { fmac8<0>(acc, hv, w); fmac8<1>(acc, hv, w + 8); fmac8<2>(acc, hv, w + 16); fmac8<3>(acc, hv, w + 24); }
+    else { fmac4<0>(acc, hv, w); fmac4<1>(acc, hv, w + 4); fmac4<2>(acc, hv, w + 8); fmac4<3>(acc, hv, w + 12); }
+}
+
+// Lane layout of a chain wave: lane = 16 R + 4 kw + j; R = 2 rq + c0.  The quad (j = 0..3) holds chain (kw, c0) of rows
+// 4 rq + j.  Operand values of a chain sit in LDS in chain order ([cid = 2 kw + c0][n]); they are used in PHASES of 32
+// terms: in phase ph quad lane j holds terms 32 ph + 8 j .. + 7 (two 16-byte LDS words), so term n comes from quad lane
+// (n % 32) / 8, register n % 8 -- 8 operand registers per phase instead of NT / 4 for the whole chain.  A last phase of 16
+// terms (NT = 112) gives every lane 4.
+template <int NT>
+__device__ __forceinline__ float chain_regs(const float *w, const float *opnd) {
+    float acc = 0.f;
+    constexpr int NPH = (NT + 31) / 32;
+    float4 cur[2], nxt[2];
+    const float4 *op = (const float4 *)opnd;            // this lane's first word of phase 0: opnd = base + cid * NT + 8 j
+    cur[0] = op[0]; cur[1] = op[1];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        constexpr int dummy = 0; (void)dummy;
+        const int len = NT - 32 * ph < 32 ? NT - 32 * ph : 32;          // 32, or 16 in the last phase of 112
+        if (ph + 1 < NPH) {
+            const int nlen = NT - 32 * (ph + 1) < 32 ? NT - 32 * (ph + 1) : 32;
+            if (nlen == 32) { nxt[0] = op[8 * (ph + 1)]; nxt[1] = op[8 * (ph + 1) + 1]; }
+            // a 16-term phase: lane j holds terms 4 j .. 4 j + 3; opnd points at word 2 j of the chain -> word 8 (ph + 1) + j is (j words back)
+            else { nxt[0] = *(const float4 *)(opnd + 32 * (ph + 1) - 4 * (int)(threadIdx.x & 3)); nxt[1] = nxt[0]; }
+        }
+        const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+        if (len == 32) chain_phase<32>(acc, hv, w + 32 * ph);
+        else chain_phase<16>(acc, hv, w + 32 * ph);
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+    }
+    return acc;
+}
+// The same chain for ONE or TWO operand vectors (two decode slots) with its weights streamed from LDS ([NT] floats at wp,
+// chain order) a phase ahead of their use: a service wave must not hold 112 weights next to everything else it keeps.
+// w0 = the weights of phase 0, already in registers (requested before the barrier the chain waits behind).
+__device__ __forceinline__ void load_phase(const float *opnd, int ph, int nlen, float4 (&d)[2]) {
+    if (nlen == 32) { d[0] = ((const float4 *)opnd)[8 * ph]; d[1] = ((const float4 *)opnd)[8 * ph + 1]; }
+    else { d[0] = *(const float4 *)(opnd + 32 * ph - 4 * (int)(threadIdx.x & 3)); d[1] = d[0]; }     // 16-term phase: lane j holds terms 4 j .. 4 j + 3
+}
+template <int NT>
+__device__ __forceinline__ void chain_lds2(const float4 *wp, const float4 (&w0)[8], const float *opA, const float *opB, bool two,
+                                           float &accA, float &accB) {
+    constexpr int NPH = (NT + 31) / 32;
+    float4 curA[2], nxtA[2], curB[2], nxtB[2], wc[8], wn[8];
+    load_phase(opA, 0, NT < 32 ? NT : 32, curA);
+    if (two) load_phase(opB, 0, NT < 32 ? NT : 32, curB);
+    else { curB[0] = curA[0]; curB[1] = curA[1]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wc[i] = w0[i];
+    accA = 0.f; accB = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        const int len = NT - 32 * ph < 32 ? NT - 32 * ph : 32;
+        if (ph + 1 < NPH) {
+            const int nlen = NT - 32 * (ph + 1) < 32 ? NT - 32 * (ph + 1) : 32;
+            load_phase(opA, ph + 1, nlen, nxtA);
+            if (two) load_phase(opB, ph + 1, nlen, nxtB);
+#pragma unroll
+            for (int i = 0; i < nlen / 4; ++i) wn[i] = wp[8 * (ph + 1) + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float wv[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wv[4 * i] = wc[i].x; wv[4 * i + 1] = wc[i].y; wv[4 * i + 2] = wc[i].z; wv[4 * i + 3] = wc[i].w; }
+        {
+            const float hv[8] = {curA[0].x, curA[0].y, curA[0].z, curA[0].w, curA[1].x, curA[1].y, curA[1].z, curA[1].w};
+            if (len == 32) chain_phase<32>(accA, hv, wv);
+            else chain_phase<16>(accA, hv, wv);
+        }
+        if (two) {
+            const float hv[8] = {curB[0].x, curB[0].y, curB[0].z, curB[0].w, curB[1].x, curB[1].y, curB[1].z, curB[1].w};
+            if (len == 32) chain_phase<32>(accB, hv, wv);
+            else chain_phase<16>(accB, hv, wv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        curA[0] = nxtA[0]; curA[1] = nxtA[1]; curB[0] = nxtB[0]; curB[1] = nxtB[1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wc[i] = wn[i];
+    }
+}
+
+// Row sum from the 8 chain lanes of a row: a0 + a1 across the two 16-lane rows of an rq pair (lane ^ 16), then
+// ((q0 + q1) + q2) + q3 along the K quarters (lane + 4, + 8, + 12 inside the row) -- the order of the MFMA kernels.
+// Meaningful in lanes with kw == 0 (either c0 row).
+__device__ __forceinline__ float chain_combine(float acc) {
+    const float o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(acc), 0x401F));     // lane ^ 16
+    const float q = acc + o;
+    const float q1 = PS_DPP(q, 0x104), q2 = PS_DPP(q, 0x108), q3 = PS_DPP(q, 0x10C);               // row_shl:4 / 8 / 12
+    return ((q + q1) + q2) + q3;
+}
+
+// position of operand column k in the chain-ordered LDS copy (inverse of chain_col): [cid][n]
+__device__ __forceinline__ int chain_pos(int NS, int k) {
+    const int S = k >> 4, kw = S / NS, s = S - kw * NS;
+    const int q = (k >> 2) & 3, c0 = k & 1, ci = (k >> 1) & 1;
+    return (2 * kw + c0) * (8 * NS) + 8 * s + 4 * ci + q;
+}
+
+struct Waiter {                      // bounded spinning shared by all sweeps of the kernel
+    unsigned *status;
+    unsigned ticks;
+    u64 t0;
+    __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memrealtime(); }
+    // true: give up (deadline passed -- status bit 0 is then set -- or somebody else already gave up)
+    __device__ __forceinline__ bool expired(unsigned spins, int lane) {
+        if ((spins & 63) != 63) return false;
+        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (u64)ticks;
+        if (late && lane == 0) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return late || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
+    }
+};
+
+// LDS carve, in floats (ints behind them)
+template <int BXT> struct Lds {
+    static constexpr int gemb = 0;                        // [NC][3][UPB]   slice of the sample-embedding table
+    static constexpr int fc1w = gemb + NC * ROWS;         // [FPB][8 chains][112]
+    static constexpr int fc2w = fc1w + FPB * HR;          // [FPB][8 chains][32]
+    static constexpr int whx = fc2w + FPB * HF;           // [4][8 chains][112]  W_hh rows 80..83 (the chain waves hold rows 0..79)
+    static constexpr int hc = whx + 4 * HR;               // [BXT][HR]  h_t, chain order
+    static constexpr int ac = hc + BXT * HR;              // [BXT][HF]  a_t, chain order
+    static constexpr int gsum = ac + BXT * HF;            // [BXT][96]  W_hh h of the owned rows [gate][unit]
+    static constexpr int noise = gsum + BXT * 96;         // [BXT][8]
+    static constexpr int mtab = noise + BXT * 8;          // [NC] mu-law decode table
+    static constexpr int bq = mtab + NC;                  // [3][32] b_hh of the owned units
+    static constexpr int hold = bq + 96;                  // [BXT][32] h_{t-1} of the owned units
+    static constexpr int gcq = hold + BXT * 32;           // [BXT][3][32] conditioning row in use
+    static constexpr int seg = gcq + BXT * 96;            // int [BXT][8] {index, row, t0, len, utt}
+    static constexpr int sinfo = seg + BXT * 8;           // int [BXT][4] {lt, utt, active} of the step in flight
+    static constexpr int ctl = sinfo + BXT * 4;           // int [4] {xcc, rank, ok, abort}
+    static constexpr int total = ctl + 4;
+};
+
+template <int BXT>
+__global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = Lds<BXT>;
+    float *gemb = smem + L::gemb, *fc1w = smem + L::fc1w, *fc2w = smem + L::fc2w, *whx = smem + L::whx, *hc = smem + L::hc,
+          *ac = smem + L::ac, *gsum = smem + L::gsum;
+    float *noise = smem + L::noise, *mtab = smem + L::mtab, *c_bq = smem + L::bq, *c_hold = smem + L::hold, *c_gc = smem + L::gcq;
+    int *seg_st = (int *)(smem + L::seg), *sinfo = (int *)(smem + L::sinfo), *s_ctl = (int *)(smem + L::ctl);
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+
+    // ---- placement: which XCD am I on, which of its 32 workers am I?
+    if (tid == 0) {
+        unsigned xid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+        xid &= 7u;
+        unsigned *ctl = (unsigned *)p.xg;
+        const unsigned r = __hip_atomic_fetch_add(ctl + xid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0; __hip_atomic_load(ctl + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+            if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > (u64)p.timeout_ticks ||
+                                       __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (ok)
+            for (int x = 0; x < 8; ++x)
+                if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
+        if (!ok) __hip_atomic_fetch_or(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0;
+    }
+    __syncthreads();
+    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[0]), rank = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    if (__builtin_amdgcn_readfirstlane(s_ctl[2]) == 0) return;
+    int bx = (p.n_slots - xcc + 7) / 8;                // slots of this XCD: xcc, xcc + 8, ...
+    bx = bx < 0 ? 0 : (bx > BXT ? BXT : bx);
+    const int n_steps = p.n_steps[xcc];
+    if (bx == 0 || n_steps <= 0) return;
+    const int agent = p.agent_stores;
+
+    u64 *gh = p.xg + CTL_WORDS / 2 + (size_t)xcc * xg_region(BXT);
+    u64 *ga = gh + xg_h(BXT), *gc = ga + xg_a(BXT);
+
+    // ---- lane geometry of the chain waves
+    const unsigned R = lane >> 4, kw = (lane >> 2) & 3u, j = lane & 3u, rq = R >> 1, c0 = R & 1u, cid = 2u * kw + c0;
+    const unsigned r8 = 4u * rq + j;                                   // row of the wave's 8
+    const bool sum_lane = (lane & 0x1Cu) == 0;                         // kw == 0, c0 == 0: holds the row sum after chain_combine
+
+    // ---- resident LDS state
+    for (unsigned e = tid; e < NC * ROWS; e += THREADS) {
+        const unsigned cls = e / ROWS, rem = e - cls * ROWS, g = rem / UPB, ul = rem - g * UPB;
+        gemb[e] = p.Gemb[(size_t)cls * 3 * HR + g * HR + UPB * rank + ul];
+    }
+    for (unsigned e = tid; e < FPB * HR; e += THREADS) {
+        const unsigned rr = e / HR, rem = e - rr * HR, cc = rem / NT_H, n = rem - cc * NT_H;
+        fc1w[e] = p.w_fc1[(size_t)(FPB * rank + rr) * HR + chain_col(HR / 64, cc >> 1, cc & 1, n)];
+    }
+    for (unsigned e = tid; e < FPB * HF; e += THREADS) {
+        const unsigned rr = e / HF, rem = e - rr * HF, cc = rem / NT_A, n = rem - cc * NT_A;
+        fc2w[e] = p.w_fc2[(size_t)(FPB * rank + rr) * HF + chain_col(HF / 64, cc >> 1, cc & 1, n)];
+    }
+    for (unsigned e = tid; e < 4 * HR; e += THREADS) {                 // W_hh rows 80..83 = gate 2 (n), units 24..27
+        const unsigned rr = e / HR, rem = e - rr * HR, cc = rem / NT_H, n = rem - cc * NT_H;
+        whx[e] = p.w_hh[(size_t)(2 * HR + UPB * rank + 24 + rr) * HR + chain_col(HR / 64, cc >> 1, cc & 1, n)];
+    }
+    for (unsigned e = tid; e < NC; e += THREADS) mtab[e] = p.mulaw_tab[e];
+    for (unsigned e = tid; e < 96; e += THREADS) { const unsigned g = e >> 5, u = e & 31; c_bq[e] = u < UPB ? p.b_hh[g * HR + UPB * rank + u] : 0.f; }
+    for (unsigned e = tid; e < BXT * 32; e += THREADS) c_hold[e] = 0.f;
+    for (unsigned e = tid; e < BXT * 96; e += THREADS) { c_gc[e] = 0.f; gsum[e] = 0.f; }
+    for (unsigned e = tid; e < BXT; e += THREADS) {
+        const XdSeg sg = (int)e < bx ? p.segs[(size_t)(xcc + 8 * e) * p.max_seg] : XdSeg{-1, 0, 0, 0u};
+        seg_st[e * 8 + 0] = 0; seg_st[e * 8 + 1] = sg.len > 0 ? sg.row : -1; seg_st[e * 8 + 2] = sg.t0; seg_st[e * 8 + 3] = sg.len;
+        seg_st[e * 8 + 4] = (int)sg.utt; seg_st[e * 8 + 5] = 0; seg_st[e * 8 + 6] = 0;      // samples into / index of the conditioning frame
+        sinfo[e * 4 + 0] = 0; sinfo[e * 4 + 1] = 0; sinfo[e * 4 + 2] = 0;
+    }
+    __syncthreads();
+
+    Waiter wt{p.status, p.timeout_ticks, 0};
+    int *s_abort = s_ctl + 3;
+
+    // h_t gather: every thread takes column tid of every slot, the first 128 threads also column 768 + tid
+    const unsigned hk1 = tid, hk2 = THREADS + (tid & 127u);
+    const unsigned hoff1 = ((((hk1 / UPB) * BXT) << 5) + hk1 % UPB) * 8u, hoff2 = ((((hk2 / UPB) * BXT) << 5) + hk2 % UPB) * 8u;
+    const unsigned hdst1 = chain_pos(HR / 64, hk1), hdst2 = chain_pos(HR / 64, hk2);
+    const bool two = tid < HR - THREADS;
+#define XD_SWEEP_H()                                                                                              \
+    do {                                                                                                          \
+        u64 v1[BXT], v2[BXT];                                                                                     \
+        wt.start();                                                                                               \
+        for (unsigned spins = 0;; ++spins) {                                                                      \
+            bool ok = true;                                                                                       \
+            gran_load<BXT, 256>(v1, gh, hoff1);                                                                   \
+            _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v1[b] >> 32) == tag;      \
+            if (wave < 2) {                                                                                       \
+                gran_load<BXT, 256>(v2, gh, hoff2);                                                               \
+                _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v2[b] >> 32) == tag;  \
+            }                                                                                                     \
+            if (__all(ok)) break;                                                                                 \
+            if (wt.expired(spins, lane)) { *s_abort = 1; break; }                                                 \
+            __builtin_amdgcn_s_sleep(1);                                                                          \
+        }                                                                                                         \
+        _Pragma("unroll") for (int b = 0; b < BXT; ++b) {                                                         \
+            if (b < bx) { hc[b * HR + hdst1] = __uint_as_float((unsigned)v1[b]); if (two) hc[b * HR + hdst2] = __uint_as_float((unsigned)v2[b]); } \
+        }                                                                                                         \
+    } while (0)
+
+    const float *opnd = hc + cid * NT_H + 8 * j;
+    if (wave < 10) {
+        // =====================================================================================  chain waves: W_hh rows 0..79
+        const unsigned row_local = 8 * wave + r8;                          // gate * UPB + unit
+        float w[NT_H];
+        {
+            const unsigned gate = row_local / UPB, ul = row_local - gate * UPB;
+            ps_load_weights<HR / 64>(p.w_hh + (size_t)(gate * HR + UPB * rank + ul) * HR, kw, c0, w);
+        }
+        for (int t = 0; t < n_steps; ++t) {
+            const unsigned tag = (unsigned)t + 1u;
+            XD_SWEEP_H();
+            ps_barrier();                                                // A: h_t in LDS
+            if (*s_abort) break;
+            for (int b = 0; b < bx; ++b) {
+                const float acc = chain_regs<NT_H>(w, opnd + b * HR);
+                const float v = chain_combine(acc);
+                if (sum_lane) gsum[b * 96 + row_local] = v;
+            }
+            XD_STAMP(0, 6);
+            ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
+            if (*s_abort) break;
+        }
+    } else {
+        // =====================================================================================  service waves
+        // Wave 11 (sv 0) owns the even slots of the XCD, wave 10 (sv 1) the odd ones, for everything that is serial in a
+        // sample step: x_{t-1} from the slot's 32 candidates, the cell update of the 28 owned units, h_t published, the
+        // draw's noise, fc1 -> a_t published, W_hh rows 80..83 (in the shadow of the a_t exchange), a_t gathered,
+        // fc2 + Gumbel-max candidate published.  Half wave hw of the cell update takes slot sv + 2 hw.
+        const int sv = 11 - wave;
+        const int hw = (int)(lane >> 5);
+        const int cb = sv + 2 * hw;                                     // slot of this half wave in the cell update
+        const unsigned cu = lane & 31u;                                 // unit
+        const int n_own = bx > sv ? (bx - sv + 1) / 2 : 0;              // slots sv, sv + 2 < bx
+        const bool cell_on = cb < bx;
+        const float b1 = p.b_fc1[FPB * rank + r8], b2 = p.b_fc2[FPB * rank + r8];
+        const float *opnd2 = ac + cid * NT_A + 8 * j;
+        const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)sv) << 3) + (lane & 7u)) * 8u;   // a_t granule of (rank lane >> 3 (+ 8 i), slot sv, row lane & 7), bytes
+        const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);   // chain_pos(4, lane + 64 i) - 64 i
+        const float4 *wp1 = (const float4 *)(fc1w + (r8 * 8 + cid) * NT_H);
+        const float4 *wpx = (const float4 *)(whx + ((r8 & 3u) * 8 + cid) * NT_H);
+        const float4 *wp2 = (const float4 *)(fc2w + (r8 * 8 + cid) * NT_A);
+        const float bq0 = c_bq[cu], bq1 = c_bq[32 + cu], bq2 = c_bq[64 + cu];
+
+        const u64 *csrc = gc + ((lane & 31u) * 16 + (unsigned)(cb < BXT ? cb : 0));
+        for (int t = 0; t < n_steps; ++t) {
+            const unsigned tag = (unsigned)t + 1u;
+            __builtin_amdgcn_s_setprio(3);
+            XD_STAMP(11, 0);
+            // ---- first look at the slot's 32 candidates (tag t): requested now, examined after the x-independent work below
+            const bool want_x = n_own > 0 && t > 0;
+            u64 g = 0;
+            if (want_x) g = ps_load(csrc);
+            // ---- everything of the cell update that does not depend on x_{t-1} (gsum of step t-1 is complete: barrier B)
+            int row = -1, lt = 0, emit_at = -1, emit_row = 0;
+            unsigned utt = 0u;
+            bool active = false, first = false;
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
+            if (cell_on) {
+                int si = seg_st[cb * 8 + 0], t0 = seg_st[cb * 8 + 2], len = seg_st[cb * 8 + 3], fpos = seg_st[cb * 8 + 5], fidx = seg_st[cb * 8 + 6];
+                row = seg_st[cb * 8 + 1];
+                utt = (unsigned)seg_st[cb * 8 + 4];
+                lt = t - t0;
+                if (row >= 0 && lt >= 1 && lt <= len) { emit_at = lt - 1; emit_row = row; }       // x_{t-1} is sample lt - 1 of `row`
+                if (row >= 0 && lt >= len) {                             // next utterance of this slot (uniform per half wave)
+                    si += 1;
+                    XdSeg sg = XdSeg{-1, 0, 0, 0u};
+                    if (si < p.max_seg) sg = p.segs[(size_t)(xcc + 8 * cb) * p.max_seg + si];
+                    row = sg.len > 0 ? sg.row : -1; t0 = sg.t0; len = sg.len; utt = sg.utt;
+                    lt = t - t0;
+                    fpos = 0; fidx = 0;
+                    if (cu == 0) { seg_st[cb * 8 + 0] = si; seg_st[cb * 8 + 1] = row; seg_st[cb * 8 + 2] = t0; seg_st[cb * 8 + 3] = len; seg_st[cb * 8 + 4] = (int)utt;
+                                   seg_st[cb * 8 + 5] = 0; seg_st[cb * 8 + 6] = 0; }
+                }
+                active = row >= 0 && lt >= 0 && lt < len;
+                first = lt == 0;
+                if (active) {
+                    if (fpos == p.upsample) { fpos = 0; fidx += 1; }
+                    if (fpos == 0 && cu < UPB) {                         // next conditioning frame (once per hop)
+                        const int f = fidx < p.F ? fidx : p.F - 1;
+                        const float *gcp = p.Gcond + ((size_t)row * p.F + f) * 3 * HR + UPB * rank + cu;
+                        g0 = gcp[0]; g1 = gcp[HR]; g2 = gcp[2 * HR];
+                        c_gc[cb * 96 + cu] = g0; c_gc[cb * 96 + 32 + cu] = g1; c_gc[cb * 96 + 64 + cu] = g2;
+                    } else { g0 = c_gc[cb * 96 + cu]; g1 = c_gc[cb * 96 + 32 + cu]; g2 = c_gc[cb * 96 + 64 + cu]; }
+                    fpos += 1;
+                    if (cu == 0) { seg_st[cb * 8 + 5] = fpos; seg_st[cb * 8 + 6] = fidx; }
+                    const float gr = first ? 0.f : gsum[cb * 96 + cu], gz = first ? 0.f : gsum[cb * 96 + UPB + cu],
+                                gn = first ? 0.f : gsum[cb * 96 + 2 * UPB + cu];
+                    hold = first ? 0.f : c_hold[cb * 32 + cu];
+                    s0 = gr + bq0; s1 = gz + bq1; sn = gn + bq2;
+                }
+            }
+            // ---- x_{t-1}
+            int x = NC / 2;
+            if (want_x) {
+                wt.start();
+                for (unsigned spins = 0;; ++spins) {
+                    if (__all(!cell_on || (unsigned)(g >> 40) == (unsigned)t)) break;
+                    if (wt.expired(spins, lane)) { *s_abort = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    g = ps_load(csrc);
+                }
+                // first argmax per half of 32 lanes (classes ascend with the rank): order-preserving integer image of the score
+                unsigned u = (unsigned)g;
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                unsigned m = u;
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));
+                const unsigned m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 16),
+                               m2 = __builtin_amdgcn_readlane(m, 32), m3 = __builtin_amdgcn_readlane(m, 48);
+                const unsigned b01 = max(m0, m1), b23 = max(m2, m3);
+                const unsigned long long hit = __ballot(u == (lane < 32 ? b01 : b23));
+                const int f0 = __ffs((int)(unsigned)hit) - 1, f1 = __ffs((int)(unsigned)(hit >> 32)) - 1;
+                const int cls = (int)((g >> 32) & 255u);
+                const int x0 = __builtin_amdgcn_readlane(cls, f0 < 0 ? 0 : f0), x1 = __builtin_amdgcn_readlane(cls, 32 + (f1 < 0 ? 0 : f1));
+                x = lane < 32 ? x0 : x1;
+            }
+            XD_STAMP(11, 1);
+            // ---- the x-dependent rest: sample out, embedding row, gates, publish h_t
+            if (cell_on) {
+                if (emit_at >= 0 && cu == 0 && rank == (cb & 31)) {      // network_vocoder.py:78 output
+                    if (p.wav) p.wav[(size_t)emit_row * p.Lout + emit_at] = mtab[x];
+                    if (p.mulaw) p.mulaw[(size_t)emit_row * p.Lout + emit_at] = x;
+                }
+                float hn = 0.f;
+                if (active && cu < UPB) {
+                    const int xe = first ? NC / 2 : x;
+                    const float e0 = gemb[(xe * 3 + 0) * UPB + cu], e1 = gemb[(xe * 3 + 1) * UPB + cu], e2 = gemb[(xe * 3 + 2) * UPB + cu];
+                    const float r = sigmoidf_((e0 + g0) + s0);
+                    const float z = sigmoidf_((e1 + g1) + s1);
+                    const float nn = tanhf((e2 + g2) + r * sn);
+                    hn = (1.0f - z) * nn + z * hold;
+                    c_hold[cb * 32 + cu] = hn;
+                }
+                if (cu < UPB) xd_put(gh, (((unsigned)(rank * BXT + cb) << 5) + cu) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
+            }
+            XD_STAMP(11, 2);
+            // ---- in the shadow of the h_t exchange: the noise of this step's draw (class lane & 7 of slot sv + 2 ((lane >> 3) & 1))
+            // and the first half of the fc1 weights
+            const int lt_b = __builtin_amdgcn_readlane(lt, 0), lt_b2 = __builtin_amdgcn_readlane(lt, 32);
+            const unsigned ut_b = __builtin_amdgcn_readlane(utt, 0), ut_b2 = __builtin_amdgcn_readlane(utt, 32);
+            if (lane < 16) {
+                const int which = (int)(lane >> 3), b = sv + 2 * which;
+                if (b < bx) {
+                    const unsigned cls = FPB * rank + (lane & 7u);
+                    const unsigned wd = philox_word((unsigned)(which ? lt_b2 : lt_b), which ? ut_b2 : ut_b, cls >> 2,
+                                                    (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
+                    noise[b * 8 + (lane & 7u)] = gumbel_from_word(wd);
+                }
+            }
+            float4 w1p[8];                                               // phase 0 of the fc1 weights
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w1p[i] = wp1[i];
+            XD_SWEEP_H();
+            XD_STAMP(11, 3);
+            ps_barrier();                                                // A: h_t in LDS
+            if (*s_abort) break;
+            XD_STAMP(11, 4);
+            // ---- fc1 of the own slots (both together: every weight is used for both and then dropped)
+            if (n_own > 0) {
+                float accA, accB;
+                chain_lds2<NT_H>(wp1, w1p, opnd + sv * HR, opnd + (sv + 2 < BXT ? sv + 2 : sv) * HR, n_own > 1, accA, accB);
+                float v = chain_combine(accA);
+                v += b1;
+                v = v > 0.f ? v : 0.f;
+                if (sum_lane) xd_put(ga, (((unsigned)(rank * BXT + sv) << 3) + r8) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
+                if (n_own > 1) {
+                    float v2 = chain_combine(accB);
+                    v2 += b1;
+                    v2 = v2 > 0.f ? v2 : 0.f;
+                    if (sum_lane) xd_put(ga, (((unsigned)(rank * BXT + sv + 2) << 3) + r8) * 8u, ((u64)tag << 32) | __float_as_uint(v2), agent);
+                }
+            }
+            XD_STAMP(11, 5);
+            XD_STAMP(10, 10);
+            // ---- W_hh rows 80..83 of the OTHER wave's slots (it is busier when it owns more): the first of them in the shadow
+            // of the a_t exchange (lanes 0..31; the upper half repeats them)
+            const int xb0 = 1 - sv;                                      // slots 1 - sv, 3 - sv
+            if (xb0 < bx) {
+                float4 wx0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wx0[i] = wpx[i];
+                float acc, unused;
+                chain_lds2<NT_H>(wpx, wx0, opnd + xb0 * HR, opnd + xb0 * HR, false, acc, unused);
+                const float v = chain_combine(acc);
+                if (sum_lane && lane < 32) gsum[xb0 * 96 + 80 + r8] = v;
+            }
+            XD_STAMP(11, 7);
+            XD_STAMP(10, 11);
+            // ---- a_t of the own slots, then fc2 + Gumbel-max candidate per slot
+            if (n_own > 0) {
+                float4 w2p[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w2p[i] = wp2[i];
+                const float nz0 = noise[sv * 8 + r8], nz1 = noise[(sv + 2 < BXT ? sv + 2 : sv) * 8 + r8];
+                u64 va[2][4];
+                wt.start();
+                for (unsigned spins = 0;; ++spins) {
+                    bool ok = true;
+                    gran_load4b<512 * BXT>(va[0], ga, ga + 128 * BXT, aoff);                            // slot sv: ranks (lane >> 3) + 8 i
+                    if (sv + 2 < bx) gran_load4b<512 * BXT>(va[1], ga, ga + 128 * BXT, aoff + 128u);    // slot sv + 2
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ok &= sv + 2 * q >= bx || (unsigned)(va[q][i] >> 32) == tag;
+                    if (__all(ok)) break;
+                    if (wt.expired(spins, lane)) { *s_abort = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int b = sv + 2 * q;
+                    if (b < bx) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ac[b * HF + 64 * i + adst] = __uint_as_float((unsigned)va[q][i]);
+                    }
+                }
+                XD_STAMP(11, 8);
+                float accq[2];
+                chain_lds2<NT_A>(wp2, w2p, opnd2 + sv * HF, opnd2 + (sv + 2 < BXT ? sv + 2 : sv) * HF, n_own > 1, accq[0], accq[1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int b = sv + 2 * q;
+                    if (b >= bx) break;
+                    float v = chain_combine(accq[q]);
+                    v += b2;
+                    const float sc = v + (q ? nz1 : nz0);                    // classes 0..3 of the 8 in lanes 0..3, 4..7 in lanes 32..35
+                    float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 0));
+                    int kb = 0;
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) {
+                        const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), k < 4 ? k : 28 + k));
+                        if (sk > best) { best = sk; kb = k; }
+                    }
+                    const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
+                    if (lane == 0 && !drop)
+                        xd_put(gc, ((unsigned)rank * 16 + b) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                }
+            }
+            XD_STAMP(11, 9);
+            // ---- the second of the other wave's slots: in the shadow of the candidate exchange
+            if (xb0 + 2 < bx) {
+                float4 wx0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wx0[i] = wpx[i];
+                float acc, unused;
+                chain_lds2<NT_H>(wpx, wx0, opnd + (xb0 + 2) * HR, opnd + (xb0 + 2) * HR, false, acc, unused);
+                const float v = chain_combine(acc);
+                if (sum_lane && lane < 32) gsum[(xb0 + 2) * 96 + 80 + r8] = v;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
+            if (*s_abort) break;
+            XD_STAMP(11, 12);
+        }
+    }
+#undef XD_SWEEP_H
+}
+
+template <int BXT>
+constexpr size_t lds_bytes() { return sizeof(float) * (size_t)Lds<BXT>::total; }
+
+template <int BXT>
+int launch_t(const XdParams &p, hipStream_t s) {
+    static bool attr = false;
+    constexpr size_t lds = lds_bytes<BXT>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)ar_xcd_kernel<BXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((ar_xcd_kernel<BXT>), dim3(8 * NW), dim3(THREADS), lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
+}  // namespace
+
+size_t xd_exchange_bytes(int bxt) { return (size_t)CTL_WORDS * 4 + (size_t)8 * xg_region(bxt) * sizeof(u64); }
+bool xd_supported(int Hr, int Hf, int n_cls) { return Hr == HR && Hf == HF && n_cls == NC; }
+int xd_pick_bxt(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= XD_MAX_BX ? 4 : 0; }
+
+int xd_launch(const XdParams &p, hipStream_t s) {
+    VQ_REQUIRE(p.bxt == 1 || p.bxt == 2 || p.bxt == 4, "xd_launch: bxt %d", p.bxt);
+    VQ_REQUIRE(p.n_slots >= 1 && p.n_slots <= 8 * p.bxt, "xd_launch: %d slots do not fit 8 x %d", p.n_slots, p.bxt);
+    HIP_TRY(hipMemsetAsync(p.xg, 0, xd_exchange_bytes(p.bxt), s));
+    switch (p.bxt) {
+        case 1: return launch_t<1>(p, s);
+        case 2: return launch_t<2>(p, s);
+        case 4: return launch_t<4>(p, s);
+        default: return launch_t<4>(p, s);
+    }
+}

@@ -1091,6 +1091,7 @@ struct vqcpc_encoder {
     float *out_w = nullptr, *out_b = nullptr;
     float *codebook = nullptr, *e2 = nullptr, *cbfrag = nullptr;
     LstmPlan *lstm = nullptr;
+    int dbg_drop = -1, dbg_timeout_ms = 1000;      // tests of the resident scan's abort path
     LnConst lnc;
     DevBuf bufA, bufB, zpre, stats;
     // fused front end (enc_fused_kernel): weights in 16x16x4 fragment order
@@ -1275,6 +1276,12 @@ extern "C" int vqcpc_encoder_set_option(vqcpc_encoder *e, const char *name, int 
         return VQCPC_OK;
     }
     if (!strcmp(name, "persistent_context")) return vq_lstm_set_persistent(e->lstm, value == 2 ? 2 : (value != 0 ? -1 : 0));
+    if (!strcmp(name, "context_debug_drop_step")) { e->dbg_drop = value; return vq_lstm_set_debug(e->lstm, e->dbg_drop, e->dbg_timeout_ms); }
+    if (!strcmp(name, "context_timeout_ms")) {
+        VQ_REQUIRE(value >= 1 && value <= 10000, "context_timeout_ms must be in [1, 10000]");
+        e->dbg_timeout_ms = value;
+        return vq_lstm_set_debug(e->lstm, e->dbg_drop, e->dbg_timeout_ms);
+    }
     vq_set_error("unknown option %s", name);
     return VQCPC_ERR_INVALID;
 }
@@ -1301,6 +1308,11 @@ extern "C" int vqcpc_encoder_encode(vqcpc_encoder *e, const float *mel, int B, i
     }
     if (c) TRY(vq_lstm_run(e->lstm, z_q, B, To, c, s));
     return VQCPC_OK;
+}
+
+extern "C" int vqcpc_encoder_check(vqcpc_encoder *e) {
+    VQ_REQUIRE(e, "vqcpc_encoder_check: null argument");
+    return vq_lstm_check(e->lstm);
 }
 
 extern "C" int vqcpc_encoder_vq_encode(vqcpc_encoder *e, const float *x, int n_rows, float *z_q, int64_t *idx,

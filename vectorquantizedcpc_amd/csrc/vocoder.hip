@@ -14,6 +14,8 @@
 // candidates reach the GRU's gate waves through in-kernel granules).  A call on a single utterance runs on the
 // persistent decoder instead (ar_persist_kernel: resident workgroups, weights in registers, no launches per sample).
 #include "common.h"
+#include "ar_shared.h"
+#include "ar_xcd.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -131,7 +133,6 @@ __device__ __forceinline__ float reduce4(float (*red)[16][17], const f32x4 &acc,
     return ((red[0][row][b] + red[1][row][b]) + red[2][row][b]) + red[3][row][b];
 }
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // ------------------------------------------------------------------------------------------
 // Sequence recurrences with a hoisted input projection (prenet bi-GRU, encoder LSTM).
@@ -234,6 +235,8 @@ struct LstmPlan {
     unsigned *abort_host = nullptr;      // pinned, host-mapped: a timed-out exchange of the persistent scan is reported by the next call
     int persistent = -1;                 // -1 auto (one utterance, H = 256), 0 off, 2 = auto with agent-scope stores forced (tests)
     bool pending = false;                // a persistent scan may have raised the flag
+    int dbg_drop_step = -1;              // tests: worker 3 skips its publish at this step -> the others time out
+    int timeout_ms = 1000;               // bound of the scan's in-kernel waits
 };
 static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s);
 void vq_lstm_plan_destroy(LstmPlan *p) {
@@ -265,6 +268,21 @@ int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih,
     return VQCPC_OK;
 }
 int vq_lstm_set_persistent(LstmPlan *p, int value) { p->persistent = value; return VQCPC_OK; }
+int vq_lstm_set_debug(LstmPlan *p, int drop_step, int timeout_ms) { p->dbg_drop_step = drop_step; p->timeout_ms = timeout_ms; return VQCPC_OK; }
+// Valid once the stream that carried the scan has been synchronised (the next call on the handle checks as well: by then
+// the flag of a still-running scan may not be set yet, which is why callers that fetch results check after their sync).
+int vq_lstm_check(LstmPlan *p) {
+    if (!p->pending) return VQCPC_OK;
+    p->pending = false;
+    if (*(volatile unsigned *)p->abort_host != 0u) {
+        *p->abort_host = 0u;
+        p->persistent = 0;
+        vq_set_error("encoder LSTM: an in-kernel exchange of the resident scan timed out (the context of that call is incomplete); "
+                     "this handle now uses one launch per time step -- call again");
+        return VQCPC_ERR_HIP;
+    }
+    return VQCPC_OK;
+}
 int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream_t s) {
     const int H = p->H, nbt = (B + 15) / 16;
     TRY(p->gi.reserve((size_t)B * T * 4 * H * sizeof(float)));
@@ -272,16 +290,7 @@ int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream
     TRY(p->hbuf.reserve(2 * hsz));
     TRY(p->cbuf.reserve(hsz));
     TRY(vq_gemm_chain(x, p->D, p->w_ih, p->bias, p->gi.as<float>(), 4 * H, B * T, 4 * H, p->D, p->D, s));
-    if (p->pending) {                    // did an earlier persistent scan report a timeout?  (no HIP call: host-mapped word)
-        p->pending = false;
-        if (*(volatile unsigned *)p->abort_host != 0u) {
-            *p->abort_host = 0u;
-            p->persistent = 0;
-            vq_set_error("encoder LSTM: an in-kernel exchange of the persistent scan timed out; this handle now uses one launch "
-                         "per time step");
-            return VQCPC_ERR_HIP;
-        }
-    }
+    TRY(vq_lstm_check(p));               // did an earlier persistent scan report a timeout?  (no HIP call: host-mapped word)
     // encode.py:42-46 calls encode() on ONE utterance at a time: that scan is a chain of T dependent 256-value exchanges,
     // 3.6 us each as launches, < 1 us each inside one resident kernel
     if (p->persistent != 0 && B == 1 && H == 256 && T >= 1) return lstm_persist_launch(p, T, out, s);
@@ -369,15 +378,13 @@ struct ArModel {               // constant per handle (baked into the captured g
     unsigned long long *a1g;   // fc1 outputs as {tag, value} granules in the hL layout of `a1` (fused level 2: fc1 in the launch too)
     unsigned *abort_dev;       // set when a candidate wait timed out: later steps stop waiting
     unsigned *abort_host;      // the same, host-mapped: the next call on the handle reports it
+    unsigned timeout_ticks;    // bound of the in-kernel candidate waits (100 MHz ticks)
+    int dbg_drop_t;            // tests: the fc2 team of row group 3, tile 0 skips its candidate publish at this step (-1: never)
     int fused;                 // 0: three launches per sample; 1: fc2 + draw ride in the GRU launch (candidates in candg);
                                // 2: fc1 rides along as well (its outputs in a1g): ONE launch per sample
     int Hr, Hf, n_cls, upsample;
 };
 
-typedef unsigned long long u64;
-__device__ __forceinline__ unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned k0, unsigned k1, int w);
-__device__ __forceinline__ u64 ps_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ps_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The 16 row-group candidates of a decode slot (row groups are in class order): request, then
 // first-argmax, split so that the request can be issued early.  (A 4-lanes-per-slot variant that
@@ -446,7 +453,7 @@ __device__ __forceinline__ f32x4 mfma_frag(const float4 (&wf)[SW], const float4 
 // call it (two barriers); threads >= 256 only take part in those.
 // Bounded wait shared by the in-kernel hand-offs: true once `deadline` has passed (the abort words are then set).
 __device__ __forceinline__ bool handoff_timed_out(const ArModel &m, u64 t0, unsigned spins, int lane) {
-    if ((spins & 255) != 255 || __builtin_amdgcn_s_memrealtime() - t0 <= 25000000ull) return false;      // 0.25 s
+    if ((spins & 255) != 255 || __builtin_amdgcn_s_memrealtime() - t0 <= (u64)m.timeout_ticks) return false;      // default 0.25 s
     if (lane == 0) {
         __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -515,7 +522,7 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
                                    (unsigned)(c.seed >> 32), cls & 3);
     // 23 random bits + 0.5: every value is exact in fp32 and strictly inside (0, 1) -- a 24-bit form rounds to 1.0f
     // at w >> 8 == 0xFFFFFF, i.e. +inf noise that wins whatever the logit is
-    const float g = -logf(-logf(((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f)));
+    const float g = gumbel_from_word(w);
     const bool live = ts >= 0 && t < c.max_t && sl.row >= 0 && lt >= 0 && lt < sl.len;
     __builtin_amdgcn_sched_barrier(0);
     if (A1G) {
@@ -567,6 +574,7 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
             if (sc[r][bb] > best) { best = sc[r][bb]; k = r; }
         if (GRANULES) {
             const unsigned tag = (unsigned)(t + 1) & 0xFFFFFFu;
+            if (!(m.dbg_drop_t >= 0 && t == m.dbg_drop_t && rg == 3 && bt == 0))
             ps_store(m.candg + ((size_t)(bt * 16 + rg) * 16 + bb), ((u64)((tag << 8) | (unsigned)(16 * rg + k)) << 32) | __float_as_uint(best));
         } else {
             m.cand_s[(size_t)bg * 16 + rg] = best;
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
                         ok &= (unsigned)(gv[q] >> 40) == tag;
                     }
                     if (__all(ok || !need)) break;
-                    if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {      // 0.25 s
+                    if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > (u64)m.timeout_ticks) {      // default 0.25 s
                         if (lane == 0) {
                             __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
                     ok &= (unsigned)(gv[qq] >> 40) == tag;
                 }
                 if (__all(ok || !need)) break;
-                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {      // 0.25 s
+                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > (u64)m.timeout_ticks) {      // default 0.25 s
                     if (lane == 0) {
                         __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1014,21 +1022,6 @@ __global__ __launch_bounds__(256) void ar_fc12_kernel(ArModel m, const ArCall *_
     else fc2_body<1, 1>(m, cp, t_local, (blockIdx.x - n1) & 15, (blockIdx.x - n1) >> 4, nbt, red, sc, threadIdx.x, true);
 }
 
-// Philox4x32-10, word `k & 3` of counter (t, utt, k >> 2, 0): the sampling protocol's stream.
-__device__ __forceinline__ unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned k0, unsigned k1, int w) {
-    unsigned c[4] = {c0, c1, c2, 0u};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return w == 0 ? c[0] : w == 1 ? c[1] : w == 2 ? c[2] : c[3];
-}
-
 // fc2 + draw as a launch of its own (plain candidate arrays; GRANULES = 1: the trailing launch of a fused replay).
 template <int GRANULES>
 __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local) {
@@ -1090,11 +1083,6 @@ struct PersistP {
     unsigned utt; u64 seed;
 };
 
-__device__ __forceinline__ void ps_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 // index of h[k] in the LDS copy: inside each 16-block, [component k % 4][k / 4 % 4], so that a chain reads the four
 // k of one MFMA as one 16-byte LDS word
 __device__ __forceinline__ int ps_perm(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -1115,19 +1103,9 @@ __device__ __forceinline__ float ps_chain(const float (&w)[8 * NS], const float4
     }
     return acc;
 }
-template <int NS>
-__device__ __forceinline__ void ps_load_weights(const float *Wrow, int kw, int c0, float (&w)[8 * NS]) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) w[8 * s + 4 * ci + kq] = Wrow[16 * (kw * NS + s) + 4 * kq + c0 + 2 * ci];
-}
 // the 8 chains of a row sit in 8 consecutive lanes (index 2 kw + a): returns, in the row's first lane, the row sum in
 // the order of the launch-per-step kernels
 // (DPP moves inside the row of 16 lanes instead of ds_bpermute round trips; only the row's first lane is meaningful)
-#define PS_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
 __device__ __forceinline__ float ps_combine(float acc, int lane) {
     (void)lane;
     const float other = PS_DPP(acc, 0xB1);             // quad_perm [1,0,3,2]: lane ^ 1
@@ -1164,7 +1142,8 @@ __device__ __forceinline__ int ps_slot(int idx, int per_blk) { return (idx / per
 
 // Sweep N granules per lane (stride 64) until every tag equals `tag`; bounded.  Returns false on timeout / abort.
 template <int N>
-__device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, int per_blk, unsigned tag, unsigned (&val)[N], unsigned *abort_flag) {
+__device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, int per_blk, unsigned tag, unsigned (&val)[N], unsigned *abort_flag,
+                                         u64 ticks = 100000000ull) {
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
     int slot[N];
 #pragma unroll
@@ -1179,7 +1158,7 @@ __device__ __forceinline__ bool ps_sweep(const u64 *g, int lane, int per_blk, un
         }
         if (__all(ok)) return true;
         if ((spins & 63) == 63) {
-            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;          // 1 s at 100 MHz
+            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > ticks;                 // default 1 s at 100 MHz
             if (late || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
                 if (late && lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return false;
@@ -1212,10 +1191,12 @@ struct LstmPersistP {
     unsigned *abort_flag;
     int T;
     int force_agent;      // tests: publish with agent-scope stores even when all workers share an XCD (the fallback path)
+    int dbg_drop_step;    // tests: worker 3 skips its publish at this step
+    unsigned timeout_ticks;
 };
 template <bool LOCAL>
 __device__ __forceinline__ void lp_store(u64 *p, u64 v) {
-    if (LOCAL) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");    // plain: stays in this XCD's L2
+    if (LOCAL) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");    // workgroup scope: leaves the CU, stays in this XCD's L2
     else ps_store(p, v);
 }
 __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistP p) {
@@ -1259,7 +1240,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistP p) {
         float hv = 0.f;
         if (t > 0 && !dead) {
             unsigned v[1];
-            if (ps_sweep<1>(gw + (size_t)((t - 1) & 1) * LP_NW * PS_PAD, lane, LP_UPB, (unsigned)t, v, p.abort_flag)) hv = __uint_as_float(v[0]);
+            if (ps_sweep<1>(gw + (size_t)((t - 1) & 1) * LP_NW * PS_PAD, lane, LP_UPB, (unsigned)t, v, p.abort_flag, (u64)p.timeout_ticks)) hv = __uint_as_float(v[0]);
             else dead = true;
         }
         hbuf[ps_perm(tid)] = hv;
@@ -1275,7 +1256,9 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistP p) {
             const float hn = og * tanhf(cst);
             const u64 gr = ((u64)(unsigned)(t + 1) << 32) | __float_as_uint(hn);
             u64 *dst = p.g + ((size_t)(t & 1) * LP_NW + blk) * PS_PAD + tid;
-            if (local) lp_store<true>(dst, gr);
+            const bool drop = p.dbg_drop_step == t && blk == 3;          // tests: the other workers' sweeps of h_t time out
+            if (drop) { }
+            else if (local) lp_store<true>(dst, gr);
             else lp_store<false>(dst, gr);
             p.out[(size_t)t * H + unit] = hn;
             if (t + 1 < p.T) { const float *gp = p.Gi + (size_t)(t + 1) * 4 * H + unit; gi0 = gp[0]; gi1 = gp[H]; gi2 = gp[2 * H]; gi3 = gp[3 * H]; }
@@ -1289,6 +1272,8 @@ static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s) {
     LstmPersistP q{};
     q.w_hh = p->w_hh; q.Gi = p->gi.as<float>(); q.out = out; q.g = p->px.as<u64>(); q.T = T;
     q.force_agent = p->persistent == 2;
+    q.dbg_drop_step = p->dbg_drop_step;
+    q.timeout_ticks = (unsigned)p->timeout_ms * 100000u;
     HIP_TRY(hipHostGetDevicePointer((void **)&q.abort_flag, p->abort_host, 0));
     hipLaunchKernelGGL(lstm_persist_kernel, dim3(8 * LP_NW), dim3(256), 0, s, q);
     HIP_TRY(hipGetLastError());
@@ -1422,7 +1407,7 @@ __global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
             if (lane >= 32 && (lane & 7) == 0) {                         // the draw's noise does not depend on the data
                 const int cls = RPB * blk + row_local;
                 const unsigned wd = philox_word((unsigned)t, p.utt, (unsigned)(cls >> 2), (unsigned)p.seed, (unsigned)(p.seed >> 32), cls & 3);
-                gum = -logf(-logf(((float)(wd >> 9) + 0.5f) * (1.0f / 8388608.0f)));
+                gum = gumbel_from_word(wd);
             }
             ps_barrier();                                                // A
             __builtin_amdgcn_s_setprio(3);                               // fc1 / fc2 are on the critical path; the W_hh chains
@@ -1663,6 +1648,16 @@ struct vqcpc_vocoder {
                                          // workgroups -- 9.9 vs 9.6 us per step at 32 utterances, 19.0 vs 15.5 at 128 (r02_gru_variants.csv)
     int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
     bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
+    // one resident decoder per XCD (ar_xcd.hip): -1 auto, 0 never, 1 whenever the dimensions allow
+    int handoff_timeout_ms = 250;        // bound of the candidate waits of the fused fc2 || GRU launch
+    int handoff_debug_drop_step = -1;    // tests: one fc2 team skips its publish at this step
+    int xcd = -1;
+    int xcd_slots = 8 * XD_MAX_BX;       // decode slots it may use (<= 8 * XD_MAX_BX); more utterances run back to back in them
+    int xcd_agent_stores = 0;            // tests / A-B: publish with agent-scope stores
+    int xcd_timeout_ms = 250;            // bound of its in-kernel waits
+    int xcd_debug_drop_step = -1;        // tests: one worker skips a candidate publish at this step -> the waits time out
+    DevBuf xd_x, xd_segs;                // exchange area, slot schedule
+    bool last_was_xcd = false;
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
@@ -1703,7 +1698,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->w_hh) (void)hipFree(v->w_hh);
     if (v->Gemb4) (void)hipFree(v->Gemb4);
     if (v->bh4) (void)hipFree(v->bh4);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->px};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->px, &v->xd_x, &v->xd_segs};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -1841,6 +1836,34 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         v->persistent = value;
         return VQCPC_OK;
     }
+    if (!strcmp(name, "handoff_timeout_ms")) {
+        VQ_REQUIRE(value >= 1 && value <= 10000, "handoff_timeout_ms must be in [1, 10000]");
+        if (value != v->handoff_timeout_ms) clear_graphs(v);
+        v->handoff_timeout_ms = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "handoff_debug_drop_step")) {
+        if (value != v->handoff_debug_drop_step) clear_graphs(v);
+        v->handoff_debug_drop_step = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcd")) {
+        VQ_REQUIRE(value >= -1 && value <= 1, "xcd must be -1 (auto), 0 or 1");
+        v->xcd = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcd_slots")) {
+        VQ_REQUIRE(value >= 1 && value <= 8 * XD_MAX_BX, "xcd_slots must be in [1, %d]", 8 * XD_MAX_BX);
+        v->xcd_slots = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcd_agent_stores")) { v->xcd_agent_stores = value != 0; return VQCPC_OK; }
+    if (!strcmp(name, "xcd_timeout_ms")) {
+        VQ_REQUIRE(value >= 1 && value <= 10000, "xcd_timeout_ms must be in [1, 10000]");
+        v->xcd_timeout_ms = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcd_debug_drop_step")) { v->xcd_debug_drop_step = value; return VQCPC_OK; }
     if (!strcmp(name, "tf_chunk_replays")) {
         VQ_REQUIRE(value >= 1 && value <= 64, "tf_chunk_replays must be in [1, 64]");
         v->tf_chunk_replays = value;
@@ -1860,16 +1883,26 @@ static void clear_graphs(vqcpc_vocoder *v);
 static int persist_check(vqcpc_vocoder *v) {
     if (!v->persist_pending) return VQCPC_OK;
     const unsigned flag = *(volatile unsigned *)v->abort_host;        // written by the kernel on a timeout; no HIP call
+    v->persist_pending = false;
     if (flag != 0) {
-        v->persist_pending = false;
         *(volatile unsigned *)v->abort_host = 0u;
         v->persistent = 0;                 // e.g. the workgroups could not all be resident: no in-kernel exchanges from now on
+        v->xcd = 0;
         if (v->fuse_fc2) { v->fuse_fc2 = 0; clear_graphs(v); }
-        vq_set_error("decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete); this handle now "
-                     "uses one launch per kernel and step (set_option persistent / fuse_fc2 to re-enable)");
+        if (flag & 2u)
+            vq_set_error("decode not run: the per-XCD decoder's workgroups were not dealt 32 to each XCD (no output was written); "
+                         "this handle now uses one launch per kernel and step -- call again (set_option xcd to re-enable)");
+        else
+            vq_set_error("decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete); this handle now "
+                         "uses one launch per kernel and step -- call again (set_option xcd / persistent / fuse_fc2 to re-enable)");
         return VQCPC_ERR_HIP;
     }
     return VQCPC_OK;
+}
+
+extern "C" int vqcpc_vocoder_check(vqcpc_vocoder *v) {
+    VQ_REQUIRE(v, "vqcpc_vocoder_check: null argument");
+    return persist_check(v);
 }
 
 extern "C" int vqcpc_vocoder_last_timing(vqcpc_vocoder *v, float *loop_ms, int *n_steps) {
@@ -2072,7 +2105,8 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     }
     // upload through the pinned arena: no synchronisation of the caller's stream
     TRY(v->stage.begin(lens.size() * sizeof(int) + (table[0].size() + table[1].size()) * sizeof(ArSlot) +
-                       (size_t)(tiles[0] + tiles[1]) * 16 * sizeof(ArSlot) + 2 * sizeof(ArCall) + 256));
+                       (size_t)(tiles[0] + tiles[1]) * 16 * sizeof(ArSlot) + 2 * sizeof(ArCall) + 256 +
+                       (size_t)8 * XD_MAX_BX * (B + 1) * sizeof(XdSeg)));
     TRY(v->stage.upload(v->len.p, lens.data(), lens.size() * sizeof(int), s));
     for (int g = 0; g < n_grp; ++g) {
         TRY(v->stage.upload(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), s));
@@ -2090,6 +2124,56 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
 
     unsigned *abort_dev_ptr = nullptr;       // device view of the host-mapped abort flag (in-kernel waits that time out)
     HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev_ptr, v->abort_host, 0));
+    // One resident, weight-stationary decoder per XCD (ar_xcd.hip): utterances dealt over the XCDs' decode slots, longest
+    // first onto the slot that frees up first; a slot runs its utterances back to back (no replay boundaries here).
+    v->last_was_xcd = false;
+    if (v->xcd != 0 && !inputs && xd_supported(Hr, d.Hf, d.n_cls) && max_t > 0 && max_t < (1 << 24)) {
+        int xs = v->xcd_slots < 1 ? 1 : v->xcd_slots;
+        if (v->n_slots > 0 && v->n_slots < xs) xs = v->n_slots;
+        int nz = 0;
+        for (int b = 0; b < B; ++b) nz += lens[Bp + b] > 0;
+        if (nz < xs) xs = nz;
+        const int bxt = xd_pick_bxt((xs + 7) / 8);
+        std::vector<long> xend(xs, 0);
+        std::vector<std::vector<XdSeg>> lists(xs);
+        for (int row : order) {
+            const int len = lens[Bp + row];
+            if (len <= 0) continue;
+            int best = 0;
+            for (int q = 1; q < xs; ++q) if (xend[q] < xend[best]) best = q;
+            lists[best].push_back(XdSeg{row, (int)xend[best], len, utt[row]});
+            xend[best] += len;
+        }
+        size_t max_seg = 1;
+        for (auto &l : lists) max_seg = l.size() + 1 > max_seg ? l.size() + 1 : max_seg;
+        std::vector<XdSeg> tab((size_t)8 * bxt * max_seg, XdSeg{-1, 0, 0, 0u});
+        XdParams xp{};
+        long longest = 0;
+        for (int q = 0; q < xs; ++q) {
+            for (size_t i = 0; i < lists[q].size(); ++i) tab[(size_t)q * max_seg + i] = lists[q][i];
+            const int x = q % 8;
+            if (xend[q] + 1 > xp.n_steps[x]) xp.n_steps[x] = (int)xend[q] + 1;
+            longest = xend[q] > longest ? xend[q] : longest;
+        }
+        VQ_REQUIRE(bxt > 0 && longest < (1L << 24), "vocoder: per-XCD schedule out of range");
+        TRY(v->xd_segs.reserve(tab.size() * sizeof(XdSeg)));
+        TRY(v->xd_x.reserve(xd_exchange_bytes(bxt)));
+        TRY(v->stage.upload(v->xd_segs.p, tab.data(), tab.size() * sizeof(XdSeg), s));
+        xp.w_hh = v->w_hh; xp.w_fc1 = v->w_fc1; xp.b_fc1 = v->b_fc1; xp.w_fc2 = v->w_fc2; xp.b_fc2 = v->b_fc2;
+        xp.Gemb = v->Gemb; xp.b_hh = v->b_hh; xp.Gcond = v->gcond.as<float>(); xp.mulaw_tab = v->mulaw_tab;
+        xp.segs = v->xd_segs.as<XdSeg>(); xp.xg = v->xd_x.as<unsigned long long>(); xp.status = abort_dev_ptr;
+        xp.wav = wav; xp.mulaw = mulaw; xp.seed = seed; xp.max_seg = (int)max_seg; xp.n_slots = xs; xp.bxt = bxt;
+        xp.Lout = Lout; xp.F = T2; xp.upsample = d.upsample_t; xp.agent_stores = v->xcd_agent_stores;
+        xp.timeout_ticks = (unsigned)v->xcd_timeout_ms * 100000u; xp.dbg_drop_step = v->xcd_debug_drop_step;
+        HIP_TRY(hipEventRecord(v->ev0, s));
+        TRY(xd_launch(xp, s));
+        HIP_TRY(hipEventRecord(v->ev1, s));
+        v->last_steps = (int)longest;
+        v->have_last = false;
+        v->persist_pending = true;
+        v->last_was_xcd = true;
+        return VQCPC_OK;
+    }
     // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
     if (v->persistent != 0 && B == 1 && !inputs && Hr == 896 && d.Hf == 256 && d.n_cls == 256 && lens[Bp] > 0 &&
         lens[Bp] < (1 << 24)) {
@@ -2162,6 +2246,8 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         m.a1g = G.a1g.as<u64>();
         m.abort_dev = (unsigned *)((char *)G.candg.p + cg_bytes);
         m.abort_host = abort_dev_ptr;
+        m.timeout_ticks = (unsigned)v->handoff_timeout_ms * 100000u;
+        m.dbg_drop_t = v->handoff_debug_drop_step;
         {
             const size_t big_lds = (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
             const bool big = v->big_min_tiles > 0 && nb >= v->big_min_tiles && Hr % 16 == 0 && big_lds <= 160 * 1024;

@@ -50,6 +50,22 @@ def make_buckets(lengths: Sequence[int], modes: Sequence[int], max_batch: int, m
     return buckets
 
 
+def generate_checked(vocoder: Vocoder, idx, spk, **kw):
+    """``Vocoder.generate`` followed by ``Vocoder.check()`` (one stream synchronisation): if an in-kernel hand-off of the
+    call timed out, the handle has fallen back to the launch-per-step kernels and the call is repeated ONCE -- same
+    sampling streams, so the same samples the fast path would have produced (``convert.py:75-83`` writes the waveform
+    right after ``generate``; nothing incomplete may reach it)."""
+    wav = vocoder.generate(idx, spk, **kw)
+    try:
+        vocoder.check()
+    except RuntimeError as e:
+        import warnings
+        warnings.warn(f"decode repeated on the fallback path: {e}")
+        wav = vocoder.generate(idx, spk, **kw)
+        vocoder.check()
+    return wav
+
+
 def _pad_stack(mels: Sequence[torch.Tensor], ids: Sequence[int], device) -> torch.Tensor:
     T = max(int(mels[i].shape[-1]) for i in ids)
     out = torch.zeros(len(ids), mels[ids[0]].shape[0], T, device=device)
@@ -71,6 +87,14 @@ def encode_utterances(encoder: Encoder, mels: Sequence[torch.Tensor], want_conte
     for ids in make_buckets(lengths, modes, max_batch, max_pad_frac):
         batch = _pad_stack(mels, ids, dev)
         z, c, idx, _ = encoder._encode_native(batch, want_c=want_context, conv_mode=modes[ids[0]])
+        if want_context:                         # the resident context scan of a one-utterance call may have given up
+            try:
+                encoder.check()
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"encode repeated on the fallback path: {e}")
+                z, c, idx, _ = encoder._encode_native(batch, want_c=True, conv_mode=modes[ids[0]])
+                encoder.check()
         for k, i in enumerate(ids):
             n = out_frames(lengths[i])
             out[i] = {"z": z[k, :n], "indices": idx[k, :n], "c": c[k, :n] if want_context else None}
@@ -105,7 +129,7 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
             continue
         n_codes = [n_codes_all[i] for i in ids]
         spk = torch.tensor([int(speakers[i]) for i in ids], device=dev)
-        wav = vocoder.generate(idx, spk, n_codes=n_codes, seed=seed, utt_ids=[utt_ids[i] for i in ids])
+        wav = generate_checked(vocoder, idx, spk, n_codes=n_codes, seed=seed, utt_ids=[utt_ids[i] for i in ids])
         for k, i in enumerate(ids):
             out[i] = wav[k, : 2 * up * n_codes[k]]
     if slots > 0:
@@ -115,7 +139,7 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
         spk = torch.tensor([int(v) for v in speakers], device=dev)
         vocoder.set_option("slots", slots)
         try:
-            wav = vocoder.generate(idx, spk, n_codes=n_codes_all, seed=seed, utt_ids=utt_ids)
+            wav = generate_checked(vocoder, idx, spk, n_codes=n_codes_all, seed=seed, utt_ids=utt_ids)
         finally:
             vocoder.set_option("slots", 0)
         for i in range(len(mels)):

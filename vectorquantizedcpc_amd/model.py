@@ -157,6 +157,8 @@ class Encoder(nn.Module):
             torch.cuda.current_stream().synchronize()
             _lib.check(_lib.load().vqcpc_encoder_create(C.byref(w), C.byref(h)))
         self._handle, self._handle_key = h, key
+        for name, value in self.__dict__.get("_options", {}).items():     # options survive a rebuild of the handle
+            _lib.check(_lib.load().vqcpc_encoder_set_option(h, name.encode(), value))
         return h
 
     def _release(self):
@@ -175,8 +177,19 @@ class Encoder(nn.Module):
         self.codebook._owner = weakref.ref(self)
 
     def set_option(self, name: str, value: int):
-        """``vqcpc_encoder_set_option`` (``fused``: -1 auto, 0 layered kernels, 1 fused front end)."""
+        """``vqcpc_encoder_set_option`` (``fused``: -1 auto, 0 layered kernels, 1 fused front end).  Options are kept on
+        the Python object and re-applied when the native handle is rebuilt (``.to()``, ``load_state_dict``)."""
         _lib.check(_lib.load().vqcpc_encoder_set_option(self._native(), name.encode(), int(value)))
+        self.__dict__.setdefault("_options", {})[name] = int(value)
+
+    def check(self):
+        """Synchronise the current stream and raise ``RuntimeError`` if the resident context scan of the last ``encode``
+        gave up on an in-kernel exchange (``vqcpc_encoder_check``): that call's ``c`` is incomplete, the handle has fallen
+        back to one launch per time step, and repeating the call gives the right result."""
+        if self._handle is None:
+            return
+        torch.cuda.current_stream().synchronize()
+        _lib.check(_lib.load().vqcpc_encoder_check(self._handle))
 
     def refresh(self):
         """Drop the native handle so that the next call re-reads the parameters.  The handle holds re-laid

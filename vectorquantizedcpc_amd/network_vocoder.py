@@ -135,6 +135,8 @@ class Vocoder(nn.Module):
             torch.cuda.current_stream().synchronize()
             _lib.check(_lib.load().vqcpc_vocoder_create(C.byref(w), C.byref(h)))
         self._handle, self._handle_key = h, key
+        for name, value in self.__dict__.get("_options", {}).items():     # options survive a rebuild of the handle
+            _lib.check(_lib.load().vqcpc_vocoder_set_option(h, name.encode(), value))
         return h
 
     def _release(self):
@@ -161,8 +163,19 @@ class Vocoder(nn.Module):
         self._handle_key = None
 
     def set_option(self, name: str, value: int):
-        """Decode-loop options of ``vqcpc_vocoder_set_option`` (``use_graph``, ``steps_per_graph``)."""
+        """Decode-loop options of ``vqcpc_vocoder_set_option`` (``use_graph``, ``steps_per_graph``, ``xcd``, ...).  They are
+        kept on the Python object and re-applied when the native handle is rebuilt (``.to()``, ``load_state_dict``)."""
         _lib.check(_lib.load().vqcpc_vocoder_set_option(self._native(), name.encode(), int(value)))
+        self.__dict__.setdefault("_options", {})[name] = int(value)
+
+    def check(self):
+        """Synchronise the current stream and raise ``RuntimeError`` if an in-kernel hand-off of the last ``generate``
+        timed out (``vqcpc_vocoder_check``): that call's waveform is incomplete, the handle has fallen back to one launch
+        per kernel and step, and repeating the call gives the samples the fast path would have produced."""
+        if self._handle is None:
+            return
+        torch.cuda.current_stream().synchronize()
+        _lib.check(_lib.load().vqcpc_vocoder_check(self._handle))
 
     def last_timing(self):
         """(milliseconds, samples) of the last decode loop, from HIP events on its stream."""

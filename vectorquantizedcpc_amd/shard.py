@@ -38,7 +38,8 @@ def gather_waveforms(wav: torch.Tensor, ids: Sequence[int], lengths: Sequence[in
     wav: (n_local, L_local) this rank's padded waveforms, row k belongs to utterance ids[k] and
     has lengths[k] valid samples.  Returns, on ``dst`` only, a list of n_total 1-D tensors in
     utterance order.  Message plan: one all_gather of (count, L) per rank, then one gather of the
-    max-padded (count_max, L_max + 2) blocks whose first two columns carry (id, length).
+    max-padded (count_max, L_max) float32 blocks and one of their (count_max, 2) int64 side tables
+    (utterance id, length) -- integers travel as integers (a float32 column is exact only below 2**24).
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [wav[ids.index(i), : lengths[ids.index(i)]] for i in range(n_total)] if len(ids) == n_total else None
@@ -49,38 +50,47 @@ def gather_waveforms(wav: torch.Tensor, ids: Sequence[int], lengths: Sequence[in
     dist.all_gather(metas, meta, group=group)
     cmax = int(max(m[0] for m in metas))
     lmax = int(max(m[1] for m in metas))
-    block = torch.zeros(cmax, lmax + 2, device=dev, dtype=torch.float32)
+    block = torch.zeros(cmax, lmax, device=dev, dtype=torch.float32)
+    side = torch.full((cmax, 2), -1, device=dev, dtype=torch.int64)
     n = wav.shape[0]
     if n:
-        block[:n, 0] = torch.tensor([float(i) for i in ids], device=dev)
-        block[:n, 1] = torch.tensor([float(v) for v in lengths], device=dev)
-        block[:n, 2: 2 + wav.shape[1]] = wav
-        block[n:, 0] = -1.0
-    else:
-        block[:, 0] = -1.0
+        side[:n, 0] = torch.tensor([int(i) for i in ids], device=dev, dtype=torch.int64)
+        side[:n, 1] = torch.tensor([int(v) for v in lengths], device=dev, dtype=torch.int64)
+        block[:n, : wav.shape[1]] = wav
     out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
+    sides = [torch.empty_like(side) for _ in range(world)] if rank == dst else None
+    dist.gather(side, sides, dst=dst, group=group)
     dist.gather(block, out, dst=dst, group=group)
     if rank != dst:
         return None
     result: List[Optional[torch.Tensor]] = [None] * n_total
     for r in range(world):
+        sd = sides[r].tolist()
         for k in range(int(metas[r][0])):
-            i, ln = int(out[r][k, 0]), int(out[r][k, 1])
-            result[i] = out[r][k, 2: 2 + ln]
+            i, ln = sd[k]
+            result[i] = out[r][k, :ln]
     return result
 
 
 def convert_sharded(mels: Sequence[torch.Tensor], speakers: Sequence[int],
                     decode_fn: Callable[[List[int], List[torch.Tensor], List[int]], torch.Tensor],
-                    samples_per_frame: int = 160, group=None, dst: int = 0):
+                    samples_per_frame: int = 160, group=None, dst: int = 0,
+                    check_fn: Optional[Callable[[], None]] = None):
     """Batched ``convert.py:52-77`` over a node: LPT-shard, decode locally, gather on ``dst``.
 
     decode_fn(ids, mels, speakers) -> (n_local, L) padded waveforms for this rank's utterances
-    (the HIP path: ``Encoder.encode_indices`` + ``Vocoder.generate``).
+    (the HIP path: ``Encoder.encode_indices`` + ``Vocoder.generate``).  ``check_fn`` (``Vocoder.check``) runs between
+    the local decode and the gather; on failure the local decode is repeated once on the fallback path.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lengths = [int(m.shape[-1]) // 2 * 2 * samples_per_frame for m in mels]
     mine = partition_lpt(lengths, world)[rank]
     wav = decode_fn(mine, [mels[i] for i in mine], [speakers[i] for i in mine])
+    if check_fn is not None:             # e.g. Vocoder.check: an aborted in-kernel hand-off must not reach the gather
+        try:
+            check_fn()
+        except RuntimeError:
+            wav = decode_fn(mine, [mels[i] for i in mine], [speakers[i] for i in mine])     # the handle has fallen back
+            check_fn()
     return gather_waveforms(wav, mine, [lengths[i] for i in mine], len(mels), dst=dst, group=group)
