@@ -27,7 +27,9 @@ def vocoder():
         sd = synth.vocoder_state_dict()
         v = V.Vocoder(V.ConfVocoder())
         v.load_state_dict(sd)
-        _cache["v"] = (v.to("cuda").eval(), sd)
+        v = v.to("cuda").eval()
+        v.set_option("xcd", 0)          # this file exercises the launch-per-step kernels and the 64-workgroup persistent decoder;
+        _cache["v"] = (v, sd)           # the per-XCD resident decoders (the default up to 64 utterances) are in test_gpu_xcd.py
     return _cache["v"]
 
 

@@ -246,7 +246,7 @@ struct Waiter {                      // bounded spinning shared by all sweeps of
     __device__ __forceinline__ bool expired(unsigned spins, int lane) {
         if ((spins & 63) != 63) return false;
         const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (u64)ticks;
-        if (late && lane == 0) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (late && lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // host-mapped: a plain store, no PCIe atomic
         return late || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
     }
 };
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         if (ok)
             for (int x = 0; x < 8; ++x)
                 if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
-        if (!ok) __hip_atomic_fetch_or(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok) __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0;
     }
     __syncthreads();
