@@ -46,10 +46,14 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic FLOP per decoded sample: W_hh 2 408 448 + embedding half of W_ih 688 128
 # + fc1 229 376 + fc2 65 536 MAC, + the conditioning half of W_ih once per 160-sample frame
 FLOP_PER_SAMPLE = 2 * (2408448 + 688128 + 229376 + 65536) + 2 * 688128 / 160.0
+# the same without the 688 128 MACs of the sample-embedding half of W_ih, which every path replaces by a 256-row table
+# lookup (Gemb): the arithmetic a decoded sample actually executes
+FLOP_EXECUTED_PER_SAMPLE = 2 * (2408448 + 229376 + 65536) + 2 * 688128 / 160.0
 FLOP_PER_FRAME = 2555904        # encoder, per output frame without the LSTM
 GRU_MAC = 2408448               # W_hh MACs per sample: the dominant kernel's algorithmic work
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-KERNEL_SOURCES = ("vectorquantizedcpc_amd/csrc/vocoder.hip", "vectorquantizedcpc_amd/csrc/common.h")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+KERNEL_SOURCES = ("vectorquantizedcpc_amd/csrc/vocoder.hip", "vectorquantizedcpc_amd/csrc/ar_xcd.hip",
+                  "vectorquantizedcpc_amd/csrc/ar_shared.h", "vectorquantizedcpc_amd/csrc/common.h")
 
 
 def log(msg):
@@ -289,13 +293,42 @@ def run_manifest(enc, voc, dev, n_utt, max_batch):
             "utterances": n_utt, "audio_seconds": samples / 16000.0, "wall_s": dt,
             "samples_per_s": samples / dt, "realtime_factor_16k": samples / 16000.0 / dt,
             "decode_loop_s": loop_ms * 1e-3, "decode_steps": int(steps), "us_per_step": loop_ms * 1e3 / max(steps, 1),
-            "slot_occupancy": samples / float(max(steps, 1) * max_batch)}
+            "slot_occupancy": samples / float(max(steps, 1) * max_batch),
+            "roofline": {"bound": "mfma", "achieved": FLOP_PER_SAMPLE * samples / (loop_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": FLOP_PER_SAMPLE * samples / (loop_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         "frac_executed": FLOP_EXECUTED_PER_SAMPLE * samples / (loop_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         "how": "6 782 976 FLOP per decoded sample x samples of the manifest / decode loop time (HIP events)"}}
 
 
-def gru_roofline(voc, n_utt, step_us):
+def gru_roofline(voc, n_utt, step_us, n_steps=0):
     """`roofline` object for the GRU-step kernel of the LAST generate() call: HIP events around 2000
     back-to-back launches on the launch stream (vqcpc_vocoder_kernel_times)."""
     step_tflops = FLOP_PER_SAMPLE * n_utt / (step_us * 1e-6) / 1e12
+    exec_frac = FLOP_EXECUTED_PER_SAMPLE / FLOP_PER_SAMPLE
+    if voc.last_path() == 2:
+        # ONE launch for the whole call: eight resident decoders, one per XCD (csrc/ar_xcd.hip).  The launch IS the decode
+        # loop, so its duration comes from the HIP events around it (vqcpc_vocoder_last_timing) and `achieved` prices every
+        # sample of the launch with SURVEY 8d's 6 782 976 FLOP.
+        steps = max(int(n_steps), 1)
+        launch_us = step_us * steps
+        flop = FLOP_PER_SAMPLE * n_utt * steps
+        return {"bound": "mfma",
+                "kernel": "ar_xcd_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD -- W_hh in VGPRs, fc1 / fc2 / "
+                          "embedding table in LDS, h_t / a_t / candidates exchanged through the XCD's own L2; fp32 VALU fma chains, "
+                          "bit-identical to the MFMA kernels)",
+                "achieved": step_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / FP32_PEAK_TFLOPS,
+                "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS,
+                "traffic": None, "flop_per_launch": flop, "avg_launch_us": launch_us, "utterances_per_launch": n_utt,
+                "samples_per_launch": n_utt * steps,
+                "algorithmic_bytes_per_launch": 4.0 * (8 * (GRU_MAC + 688128 + 229376 + 65536) + n_utt * steps) + 4.0 * n_utt * (steps // 160 + 1) * 2688,
+                "how": "HIP events on the launch stream around the one launch of the call (vqcpc_vocoder_last_timing); flop = "
+                       "6 782 976 per decoded sample x samples of the launch; algorithmic bytes = one copy of the recurrent weights "
+                       "per XCD + the conditioning rows + the waveform",
+                "launches_per_sample": 1.0 / (n_utt * steps),
+                "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
+                                "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS, "flop": FLOP_PER_SAMPLE * n_utt,
+                                "how": "the launch's duration / samples per utterance; frac_executed leaves out the 688 128 MACs per "
+                                       "sample of the embedding half of W_ih, which is a table lookup on every path"}}
     try:
         gru_us, fc1_us, fc2_us, per_launch, kind = voc.kernel_times(2000)
     except RuntimeError:
@@ -333,8 +366,10 @@ def gru_roofline(voc, n_utt, step_us):
             "other_kernels_us": {"ar_fc1_kernel" + (" (as its own launch, not on the fused path)" if whole else ""): fc1_us,
                                  "ar_fc2_kernel" + (" (as its own launch, not on the fused path)" if fused else ""): fc2_us},
             "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
+                            "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS,
                             "flop": FLOP_PER_SAMPLE * n_utt,
-                            "how": "HIP events around the whole decode loop / samples per utterance"}}
+                            "how": "HIP events around the whole decode loop / samples per utterance; frac_executed leaves out the "
+                                   "688 128 MACs per sample of the embedding half of W_ih (a table lookup on every path)"}}
 
 
 def attach_traffic(roof):
@@ -352,7 +387,13 @@ def attach_traffic(roof):
     if roof.get("avg_launch_us") is None or pmc.get("utterances") != roof["utterances_per_launch"]:
         roof["traffic_source"] = "offline file covers another batch size"
         return
+    if ("ar_xcd" in pmc.get("kernel", "")) != ("ar_xcd" in roof["kernel"]):
+        roof["traffic_source"] = "offline file covers another kernel"
+        return
     roof["traffic"] = pmc["traffic_bytes_per_launch"]
+    if "samples_per_launch" in pmc and roof.get("samples_per_launch"):      # a one-launch-per-call kernel: scale to this call's length
+        roof["traffic_measured_on_samples_per_launch"] = pmc["samples_per_launch"]
+        roof["traffic_bytes_per_sample_step"] = pmc["traffic_bytes_per_launch"] / (pmc["samples_per_launch"] / pmc["utterances"])
     roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; mostly Infinity-Cache hits)"
     roof["traffic_source"] = (f"offline: tools/collect_traffic.py -> {os.path.relpath(TRAFFIC_JSON, ROOT)} "
                               f"(kernel sources {pmc['kernel_source_sha']}, {pmc.get('launch_mode', '?')} launches, "
@@ -432,12 +473,13 @@ def main():
 
     log(f"models built; timing {args.steps} step(s) of {Bp} utterances x {L} samples on {world} GPU(s)")
     dt = timed(step, args.steps, args.warmup, dev, world)
+    voc.check()                                               # an in-kernel hand-off that gave up anywhere in the timed steps is an error
     log(f"timed region done: {dt:.3f} s")
     samples = n_total * L * args.steps
     value = samples / dt
     loop_ms, n_loop = voc.last_timing()                       # HIP events around the last decode loop
     step_us = loop_ms * 1e3 / max(n_loop, 1)
-    roof = gru_roofline(voc, Bp, step_us)
+    roof = gru_roofline(voc, Bp, step_us, n_loop)
     attach_traffic(roof)
 
     result = {
@@ -477,13 +519,16 @@ def main():
         d1, _ = wall(lambda: enc.encode_indices(m1), dev, 50)
         enc.encode(m1)
         d1c, _ = wall(lambda: enc.encode(m1), dev, 20)
+        enc.encode(m2)
+        d2c, _ = wall(lambda: enc.encode(m2), dev, 20)
         result["encoder"] = {"workload": "BASELINE configs[1]: 64 x 80 x 128 mel -> 4096 code frames",
                              "frames_per_s": fps, "ms": de * 1e3,
                              "tflops": FLOP_PER_FRAME * fps / 1e12,
                              "frac_fp32_peak": FLOP_PER_FRAME * fps / 1e12 / FP32_PEAK_TFLOPS,
                              "algorithmic_GBps": alg_bytes / de / 1e9,
                              "frac_hbm_peak": alg_bytes / de / 1e9 / HBM_PEAK_GBS,
-                             "c1_1x200_ms": d1 * 1e3, "c1_1x200_with_context_ms": d1c * 1e3}
+                             "c1_1x200_ms": d1 * 1e3, "c1_1x200_with_context_ms": d1c * 1e3,
+                             "c2_with_context_ms": d2c * 1e3}
         # BASELINE configs[2]: one utterance of 32 000 samples
         z1 = synth.randint("bench/c3", (1, 100), 512).to(dev)
         s1 = torch.zeros(1, dtype=torch.long, device=dev)
@@ -502,7 +547,7 @@ def main():
         step256()
         d256, _ = wall(step256, dev)
         ms256, n256_loop = voc.last_timing()
-        r256 = gru_roofline(voc, n256, ms256 * 1e3 / max(n256_loop, 1))
+        r256 = gru_roofline(voc, n256, ms256 * 1e3 / max(n256_loop, 1), n256_loop)
         r256["traffic_source"] = "none"
         result["one_gpu_256"] = {"workload": f"BASELINE configs[3] unsharded: {n256} utterances x {L} samples on one GPU "
                                              "(two tile groups of 128 on two streams)",

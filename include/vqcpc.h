@@ -241,6 +241,11 @@ int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
  * cli.convert and shard.convert_sharded call this before anything is written or gathered. */
 int vqcpc_vocoder_check(vqcpc_vocoder *voc);
 
+/* Which decode loop the last generate()/logits() call on the handle ran (measurement and tests; the samples do not depend
+ * on it): 0 = launch-per-step kernels, 1 = the 64-workgroup persistent single-utterance decoder, 2 = the per-XCD resident
+ * decoders; -1 = null handle. */
+int vqcpc_vocoder_last_path(vqcpc_vocoder *voc);
+
 /* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call
  * (HIP events on the launch stream) and the number of samples per utterance it covers.
  * Valid after the stream has been synchronised. */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM-side traffic per launch of the dominant decode kernel, from rocprofv3 PMC counters (GPU box only).
 
-    python3 tools/collect_traffic.py [--utterances 32] [--mode graph16|eager]
+    python3 tools/collect_traffic.py [--utterances 32] [--mode xcd|graph16|eager]
 
 Runs separate `rocprofv3 --pmc` passes (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum TCC_MISS_sum -- they do not fit one pass,
 MI355X_MICROARCH.md "rocprofv3 PMC slots") over a short decode of `--utterances` concurrent utterances and writes
@@ -9,7 +9,8 @@ profiles/r02_pmc_traffic.json: per-launch averages of the GRU-step kernel, the g
 (MI355X_MICROARCH.md "HBM"), and `kernel_source_sha` = the hash bench.py checks before it reports `roofline.traffic`
 (a file measured on other kernel sources is refused there).
 
-Launch mode: `graph16` replays the per-sample kernels from a hipGraph of 16 steps (the shipped path, shorter replay);
+Launch mode: `xcd` (default) = the per-XCD resident decoders, ONE launch per call (csrc/ar_xcd.hip), measured on a call of
+`--codes` codes per utterance (default 25 = 8 000 samples); `graph16` replays the per-sample kernels from a hipGraph of 16 steps (the shipped path, shorter replay);
 `eager` launches the same kernels one by one.  The shipped 160-step replay cannot be profiled with --pmc on ROCm 7.2:
 rocprofiler-sdk faults in its packet interceptor when the HSA intercept queue overflows (DESIGN.md "Measurement").
 The parent process never touches the GPU; each pass is a fresh child under rocprofv3.
@@ -34,14 +35,18 @@ def target(mode, n_utt, codes):
     voc = V.Vocoder(V.ConfVocoder())
     voc.load_state_dict(synth.vocoder_state_dict())
     voc = voc.cuda().eval()
-    if mode == "eager":
+    if mode == "xcd":
+        voc.set_option("xcd", 1)
+    elif mode == "eager":
+        voc.set_option("xcd", 0)
         voc.set_option("use_graph", 0)
     else:
+        voc.set_option("xcd", 0)
         voc.set_option("steps_per_graph", int(mode[len("graph"):] or 160))
     z = synth.randint("traffic/z", (n_utt, codes), 512).cuda()
     spk = (torch.arange(n_utt) % 102).cuda()
     wav = voc.generate(z, spk, seed=13, utt_base=0)
-    torch.cuda.synchronize()
+    voc.check()
     print(f"[traffic target] {mode}: {n_utt} x {wav.shape[1]} samples done", file=sys.stderr, flush=True)
 
 
@@ -60,11 +65,13 @@ def averages(out_dir, needle):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utterances", type=int, default=32)
-    ap.add_argument("--codes", type=int, default=1, help="codes per utterance (1 = 320 samples: plenty of launches)")
-    ap.add_argument("--mode", default="graph16")
+    ap.add_argument("--codes", type=int, default=0, help="codes per utterance (default: 25 = 8 000 samples for xcd, 1 = 320 samples = plenty of launches otherwise)")
+    ap.add_argument("--mode", default="xcd")
     ap.add_argument("--target", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
     args = ap.parse_args()
+    if args.codes <= 0:
+        args.codes = 25 if args.mode == "xcd" else 1
     if args.target:
         return target(args.mode, args.utterances, args.codes)
 
@@ -84,21 +91,25 @@ def main():
         if rc != 0:
             print(f"[collect_traffic] pass {name} failed with status {rc}: see {log.name}", file=sys.stderr)
             return 1
-        res.update(averages(out_dir, "ar_gru"))
+        res.update(averages(out_dir, "ar_xcd" if args.mode == "xcd" else "ar_gru"))
     kernels = sorted({k for k, _ in res})
     if not kernels:
-        print("[collect_traffic] no ar_gru dispatch in the counter files", file=sys.stderr)
+        print("[collect_traffic] no dispatch of the decode kernel in the counter files", file=sys.stderr)
         return 1
     kern = max(kernels, key=lambda k: res.get((k, "FETCH_SIZE"), (0, 0))[0])
     fetch_kb, write_kb = res[(kern, "FETCH_SIZE")][1], res[(kern, "WRITE_SIZE")][1]
     hit, miss = res[(kern, "TCC_HIT_sum")][1], res[(kern, "TCC_MISS_sum")][1]
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
     alg = 4.0 * (2408448 + args.utterances * (2 * 896 + 2 * 3 * 896))
-    if ", 1>" in kern or ", 2>" in kern:   # fused launch: fc2 + draw of the previous sample rides along (W_fc2 once, fc1 outputs per utterance)
+    steps = 320 * args.codes
+    if args.mode == "xcd":                # one launch per call: a copy of the recurrent weights per XCD + conditioning rows + waveform
+        alg = 4.0 * (8 * (2408448 + 688128 + 229376 + 65536) + args.utterances * steps) + 4.0 * args.utterances * (steps // 160 + 1) * 2688
+    elif ", 1>" in kern or ", 2>" in kern:   # fused launch: fc2 + draw of the previous sample rides along (W_fc2 once, fc1 outputs per utterance)
         alg += 4.0 * (65536 + args.utterances * 256)
-    if ", 2>" in kern:                    # ... and fc1 (W_fc1 once; the state it reads is the one the GRU reads)
+    if args.mode != "xcd" and ", 2>" in kern:                    # ... and fc1 (W_fc1 once; the state it reads is the one the GRU reads)
         alg += 4.0 * 229376
     out = {"kernel": kern, "utterances": args.utterances, "launch_mode": args.mode,
+           "samples_per_launch": args.utterances * steps if args.mode == "xcd" else args.utterances,
            "dispatches_averaged": res[(kern, "FETCH_SIZE")][0],
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "TCC_HIT_sum": hit, "TCC_MISS_sum": miss, "l2_hit_rate": hit / max(hit + miss, 1.0),

@@ -14,7 +14,7 @@ SYMBOLS = [
     "vqcpc_abi_version", "vqcpc_last_error", "vqcpc_device_count",
     "vqcpc_encoder_create", "vqcpc_encoder_destroy", "vqcpc_encoder_encode",
     "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage", "vqcpc_encoder_vq_encode", "vqcpc_encoder_set_option",
-    "vqcpc_encoder_check", "vqcpc_vocoder_check",
+    "vqcpc_encoder_check", "vqcpc_vocoder_check", "vqcpc_vocoder_last_path",
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
@@ -74,6 +74,7 @@ def load():
     lib.vqcpc_encoder_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.vqcpc_encoder_check.argtypes = [vp]
     lib.vqcpc_vocoder_check.argtypes = [vp]
+    lib.vqcpc_vocoder_last_path.argtypes = [vp]
     lib.vqcpc_vocoder_create.argtypes = [C.POINTER(VocoderWeights), C.POINTER(vp)]
     lib.vqcpc_vocoder_destroy.argtypes = [vp]
     lib.vqcpc_vocoder_destroy.restype = None

@@ -1900,6 +1900,11 @@ static int persist_check(vqcpc_vocoder *v) {
     return VQCPC_OK;
 }
 
+extern "C" int vqcpc_vocoder_last_path(vqcpc_vocoder *v) {
+    if (!v) return -1;
+    return v->last_was_xcd ? 2 : (v->have_last ? 0 : 1);
+}
+
 extern "C" int vqcpc_vocoder_check(vqcpc_vocoder *v) {
     VQ_REQUIRE(v, "vqcpc_vocoder_check: null argument");
     return persist_check(v);

@@ -184,6 +184,11 @@ class Vocoder(nn.Module):
         _lib.check(_lib.load().vqcpc_vocoder_last_timing(self._native(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_path(self) -> int:
+        """Decode loop of the last call: 0 launch-per-step kernels, 1 the 64-workgroup persistent decoder, 2 the per-XCD
+        resident decoders (``vqcpc_vocoder_last_path``)."""
+        return int(_lib.load().vqcpc_vocoder_last_path(self._native()))
+
     def kernel_times(self, reps: int = 1000):
         """(us GRU step, us fc1, us fc2 + draw, decode slots per launch, GRU kernel kind): ``vqcpc_vocoder_kernel_times``."""
         out = (C.c_float * 5)()
