@@ -22,9 +22,10 @@
 // Roles of the 12 waves of a workgroup:
 //   waves 0..9   W_hh h_t chains of rows 0..79 for every slot of the XCD (8 rows per wave, weights pinned in VGPRs) -> gsum
 //   wave 11 / 10 everything that is serial in a sample step, for the even / odd slots: x_{t-1} from the slot's 32
-//                candidates; cell update of the 28 owned units; publish h_t; the draw's noise; fc1 (weights re-read
-//                from LDS every step) -> publish a_t; sweep of a_t; fc2 + Gumbel-max candidate -> publish; and, in the
-//                shadows of the a_t and the candidate exchanges, W_hh rows 80..83 for the OTHER wave's slots
+//                candidates; cell update of the 28 owned units; publish h_t; fc1 (weights streamed from LDS) -> publish
+//                a_t; sweep of a_t; fc2 + Gumbel-max candidate -> publish; and, in the shadow of the a_t exchange, W_hh
+//                rows 80..83 for the OTHER wave's slots (one chain pass: a half wave per slot)
+//   wave 0       also draws the next step's Gumbel noise (Philox + two logs per class) in its idle time
 //   all waves    sweep h_t into LDS
 // Two workgroup barriers per sample.  Every wait is wall-clock bounded; a timeout sets status bit 0, every workgroup
 // leaves, and the call's outputs are incomplete (vqcpc_vocoder_check reports it).
@@ -94,6 +95,33 @@ __device__ __forceinline__ void gran_load4b(u64 (&v)[4], const u64 *base, const 
     asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5 sc1\n\tglobal_load_dwordx2 %1, %4, %5 offset:%7 sc1\n\t"
                  "global_load_dwordx2 %2, %4, %6 sc1\n\tglobal_load_dwordx2 %3, %4, %6 offset:%7 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(base), "s"(base2), "i"(STEP) : "memory");
+}
+template <int STEP>     // the same for two slots (second slot SLOT2 bytes further): eight granules in flight together
+__device__ __forceinline__ void gran_load8b(u64 (&v)[2][4], const u64 *base, const u64 *base2, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %8, %9 sc1\n\tglobal_load_dwordx2 %1, %8, %9 offset:%11 sc1\n\t"
+                 "global_load_dwordx2 %2, %8, %10 sc1\n\tglobal_load_dwordx2 %3, %8, %10 offset:%11 sc1\n\t"
+                 "global_load_dwordx2 %4, %8, %9 offset:128 sc1\n\tglobal_load_dwordx2 %5, %8, %9 offset:%12 sc1\n\t"
+                 "global_load_dwordx2 %6, %8, %10 offset:128 sc1\n\tglobal_load_dwordx2 %7, %8, %10 offset:%12 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])
+                 : "v"(off), "s"(base), "s"(base2), "i"(STEP), "i"(STEP + 128) : "memory");
+}
+// 2 N granules: N at `off` + i STEP and N at `off2` + i STEP, all in flight together
+template <int N, int STEP>
+__device__ __forceinline__ void gran_load_pair(u64 (&a)[N], u64 (&b)[N], const u64 *base, unsigned off, unsigned off2) {
+    if constexpr (N == 1)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %4 sc1\n\tglobal_load_dwordx2 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a[0]), "=&v"(b[0]) : "v"(off), "v"(off2), "s"(base) : "memory");
+    if constexpr (N == 2)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %6 sc1\n\tglobal_load_dwordx2 %1, %4, %6 offset:%7 sc1\n\t"
+                     "global_load_dwordx2 %2, %5, %6 sc1\n\tglobal_load_dwordx2 %3, %5, %6 offset:%7 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(b[0]), "=&v"(b[1]) : "v"(off), "v"(off2), "s"(base), "i"(STEP) : "memory");
+    if constexpr (N == 4)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %8, %10 sc1\n\tglobal_load_dwordx2 %1, %8, %10 offset:%11 sc1\n\t"
+                     "global_load_dwordx2 %2, %8, %10 offset:%12 sc1\n\tglobal_load_dwordx2 %3, %8, %10 offset:%13 sc1\n\t"
+                     "global_load_dwordx2 %4, %9, %10 sc1\n\tglobal_load_dwordx2 %5, %9, %10 offset:%11 sc1\n\t"
+                     "global_load_dwordx2 %6, %9, %10 offset:%12 sc1\n\tglobal_load_dwordx2 %7, %9, %10 offset:%13 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                     : "v"(off), "v"(off2), "s"(base), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP) : "memory");
 }
 template <int N, int STEP>
 __device__ __forceinline__ void gran_load(u64 (&v)[N], const u64 *base, unsigned off) {
@@ -260,8 +288,8 @@ template <int BXT> struct Lds {
     static constexpr int hc = whx + 4 * HR;               // [BXT][HR]  h_t, chain order
     static constexpr int ac = hc + BXT * HR;              // [BXT][HF]  a_t, chain order
     static constexpr int gsum = ac + BXT * HF;            // [BXT][96]  W_hh h of the owned rows [gate][unit]
-    static constexpr int noise = gsum + BXT * 96;         // [BXT][8]
-    static constexpr int mtab = noise + BXT * 8;          // [NC] mu-law decode table
+    static constexpr int noise = gsum + BXT * 96;         // [2][BXT][8] Gumbel noise of the step in flight / the next one
+    static constexpr int mtab = noise + 2 * BXT * 8;      // [NC] mu-law decode table
     static constexpr int bq = mtab + NC;                  // [3][32] b_hh of the owned units
     static constexpr int hold = bq + 96;                  // [BXT][32] h_{t-1} of the owned units
     static constexpr int gcq = hold + BXT * 32;           // [BXT][3][32] conditioning row in use
@@ -364,12 +392,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         wt.start();                                                                                               \
         for (unsigned spins = 0;; ++spins) {                                                                      \
             bool ok = true;                                                                                       \
-            gran_load<BXT, 256>(v1, gh, hoff1);                                                                   \
-            _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v1[b] >> 32) == tag;      \
             if (wave < 2) {                                                                                       \
-                gran_load<BXT, 256>(v2, gh, hoff2);                                                               \
+                gran_load_pair<BXT, 256>(v1, v2, gh, hoff1, hoff2);                                               \
                 _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v2[b] >> 32) == tag;  \
-            }                                                                                                     \
+            } else gran_load<BXT, 256>(v1, gh, hoff1);                                                            \
+            _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v1[b] >> 32) == tag;      \
             if (__all(ok)) break;                                                                                 \
             if (wt.expired(spins, lane)) { *s_abort = 1; break; }                                                 \
             __builtin_amdgcn_s_sleep(1);                                                                          \
@@ -388,6 +415,16 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             const unsigned gate = row_local / UPB, ul = row_local - gate * UPB;
             ps_load_weights<HR / 64>(p.w_hh + (size_t)(gate * HR + UPB * rank + ul) * HR, kw, c0, w);
         }
+        // wave 0 also draws the Gumbel noise of the NEXT step in its idle time (class lane & 7 of slot lane >> 3): it does
+        // not depend on the data, only on (sample index, utterance) of the slot, which the service waves post in sinfo
+        const unsigned ncls = FPB * rank + (lane & 7u);
+        const int nb = (int)(lane >> 3);
+        ps_barrier();                                                      // state of step 0 posted
+        if (wave == 0 && nb < bx) {
+            const unsigned wd = philox_word((unsigned)sinfo[nb * 4 + 0], (unsigned)sinfo[nb * 4 + 1], ncls >> 2, (unsigned)p.seed,
+                                            (unsigned)(p.seed >> 32), (int)(ncls & 3u));
+            noise[nb * 8 + (lane & 7u)] = gumbel_from_word(wd);
+        }
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
             XD_SWEEP_H();
@@ -398,6 +435,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 const float v = chain_combine(acc);
                 if (sum_lane) gsum[b * 96 + row_local] = v;
             }
+            if (wave == 0 && nb < bx) {                                  // noise of step t + 1 into the other buffer
+                const unsigned wd = philox_word((unsigned)sinfo[nb * 4 + 0], (unsigned)sinfo[nb * 4 + 1], ncls >> 2, (unsigned)p.seed,
+                                                (unsigned)(p.seed >> 32), (int)(ncls & 3u));
+                noise[((t + 1) & 1) * (BXT * 8) + nb * 8 + (lane & 7u)] = gumbel_from_word(wd);
+            }
             XD_STAMP(0, 6);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
             if (*s_abort) break;
@@ -405,9 +447,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     } else {
         // =====================================================================================  service waves
         // Wave 11 (sv 0) owns the even slots of the XCD, wave 10 (sv 1) the odd ones, for everything that is serial in a
-        // sample step: x_{t-1} from the slot's 32 candidates, the cell update of the 28 owned units, h_t published, the
-        // draw's noise, fc1 -> a_t published, W_hh rows 80..83 (in the shadow of the a_t exchange), a_t gathered,
-        // fc2 + Gumbel-max candidate published.  Half wave hw of the cell update takes slot sv + 2 hw.
+        // sample step: x_{t-1} from the slot's 32 candidates, the cell update of the 28 owned units, h_t published,
+        // fc1 -> a_t published, a_t gathered, fc2 + Gumbel-max candidate published; and, in the shadow of the a_t exchange,
+        // W_hh rows 80..83 for the OTHER wave's slots.  Half wave hw of the cell update takes slot sv + 2 hw.
         const int sv = 11 - wave;
         const int hw = (int)(lane >> 5);
         const int cb = sv + 2 * hw;                                     // slot of this half wave in the cell update
@@ -422,55 +464,66 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         const float4 *wpx = (const float4 *)(whx + ((r8 & 3u) * 8 + cid) * NT_H);
         const float4 *wp2 = (const float4 *)(fc2w + (r8 * 8 + cid) * NT_A);
         const float bq0 = c_bq[cu], bq1 = c_bq[32 + cu], bq2 = c_bq[64 + cu];
-
         const u64 *csrc = gc + ((lane & 31u) * 16 + (unsigned)(cb < BXT ? cb : 0));
+        // W_hh rows 80..83 for the other wave's slots 1 - sv and 3 - sv: the lower half wave takes the first, the upper half the second
+        const int xb0 = 1 - sv;
+        const bool x_two = xb0 + 2 < bx;
+        const int xslot = xb0 + ((hw && x_two) ? 2 : 0);
+        const float *opndx = opnd + xslot * HR;
+
+        // ---- slot state, one step ahead: what the cell update of step `tn` will need that does not depend on the data
+        bool st_active = false, st_first = false, st_emit = false;
+        int st_erow = 0, st_eidx = 0;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, hprev = 0.f;
+        auto advance = [&](int tn) {
+            st_active = false; st_first = false; st_emit = false;
+            if (!cell_on) return;
+            int si = seg_st[cb * 8 + 0], row = seg_st[cb * 8 + 1], t0 = seg_st[cb * 8 + 2], len = seg_st[cb * 8 + 3];
+            int fpos = seg_st[cb * 8 + 5], fidx = seg_st[cb * 8 + 6];
+            unsigned utt = (unsigned)seg_st[cb * 8 + 4];
+            int lt = tn - t0;
+            if (row >= 0 && lt >= 1 && lt <= len) { st_emit = true; st_erow = row; st_eidx = lt - 1; }    // x_{tn-1} is sample lt - 1 of `row`
+            if (row >= 0 && lt >= len) {                             // next utterance of this slot (uniform per half wave)
+                si += 1;
+                XdSeg sg = XdSeg{-1, 0, 0, 0u};
+                if (si < p.max_seg) sg = p.segs[(size_t)(xcc + 8 * cb) * p.max_seg + si];
+                row = sg.len > 0 ? sg.row : -1; t0 = sg.t0; len = sg.len; utt = sg.utt;
+                lt = tn - t0;
+                fpos = 0; fidx = 0;
+                if (cu == 0) { seg_st[cb * 8 + 0] = si; seg_st[cb * 8 + 1] = row; seg_st[cb * 8 + 2] = t0; seg_st[cb * 8 + 3] = len; seg_st[cb * 8 + 4] = (int)utt;
+                               seg_st[cb * 8 + 5] = 0; seg_st[cb * 8 + 6] = 0; }
+            }
+            st_active = row >= 0 && lt >= 0 && lt < len;
+            st_first = lt == 0;
+            if (st_active) {
+                if (fpos == p.upsample) { fpos = 0; fidx += 1; }
+                if (fpos == 0 && cu < UPB) {                         // next conditioning frame (once per hop)
+                    const int f = fidx < p.F ? fidx : p.F - 1;
+                    const float *gcp = p.Gcond + ((size_t)row * p.F + f) * 3 * HR + UPB * rank + cu;
+                    g0 = gcp[0]; g1 = gcp[HR]; g2 = gcp[2 * HR];
+                }
+                fpos += 1;
+                if (cu == 0) { seg_st[cb * 8 + 5] = fpos; seg_st[cb * 8 + 6] = fidx; }
+            }
+            if (cu == 0) { sinfo[cb * 4 + 0] = lt; sinfo[cb * 4 + 1] = (int)utt; }
+        };
+        advance(0);
+        ps_barrier();                                                    // state of step 0 posted (wave 0 draws the noise of step 0)
+
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
             __builtin_amdgcn_s_setprio(3);
             XD_STAMP(11, 0);
-            // ---- first look at the slot's 32 candidates (tag t): requested now, examined after the x-independent work below
+            // ---- first look at the slot's 32 candidates (tag t): requested now, examined after the gsum reads below
             const bool want_x = n_own > 0 && t > 0;
             u64 g = 0;
             if (want_x) g = ps_load(csrc);
-            // ---- everything of the cell update that does not depend on x_{t-1} (gsum of step t-1 is complete: barrier B)
-            int row = -1, lt = 0, emit_at = -1, emit_row = 0;
-            unsigned utt = 0u;
-            bool active = false, first = false;
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f, s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
-            if (cell_on) {
-                int si = seg_st[cb * 8 + 0], t0 = seg_st[cb * 8 + 2], len = seg_st[cb * 8 + 3], fpos = seg_st[cb * 8 + 5], fidx = seg_st[cb * 8 + 6];
-                row = seg_st[cb * 8 + 1];
-                utt = (unsigned)seg_st[cb * 8 + 4];
-                lt = t - t0;
-                if (row >= 0 && lt >= 1 && lt <= len) { emit_at = lt - 1; emit_row = row; }       // x_{t-1} is sample lt - 1 of `row`
-                if (row >= 0 && lt >= len) {                             // next utterance of this slot (uniform per half wave)
-                    si += 1;
-                    XdSeg sg = XdSeg{-1, 0, 0, 0u};
-                    if (si < p.max_seg) sg = p.segs[(size_t)(xcc + 8 * cb) * p.max_seg + si];
-                    row = sg.len > 0 ? sg.row : -1; t0 = sg.t0; len = sg.len; utt = sg.utt;
-                    lt = t - t0;
-                    fpos = 0; fidx = 0;
-                    if (cu == 0) { seg_st[cb * 8 + 0] = si; seg_st[cb * 8 + 1] = row; seg_st[cb * 8 + 2] = t0; seg_st[cb * 8 + 3] = len; seg_st[cb * 8 + 4] = (int)utt;
-                                   seg_st[cb * 8 + 5] = 0; seg_st[cb * 8 + 6] = 0; }
-                }
-                active = row >= 0 && lt >= 0 && lt < len;
-                first = lt == 0;
-                if (active) {
-                    if (fpos == p.upsample) { fpos = 0; fidx += 1; }
-                    if (fpos == 0 && cu < UPB) {                         // next conditioning frame (once per hop)
-                        const int f = fidx < p.F ? fidx : p.F - 1;
-                        const float *gcp = p.Gcond + ((size_t)row * p.F + f) * 3 * HR + UPB * rank + cu;
-                        g0 = gcp[0]; g1 = gcp[HR]; g2 = gcp[2 * HR];
-                        c_gc[cb * 96 + cu] = g0; c_gc[cb * 96 + 32 + cu] = g1; c_gc[cb * 96 + 64 + cu] = g2;
-                    } else { g0 = c_gc[cb * 96 + cu]; g1 = c_gc[cb * 96 + 32 + cu]; g2 = c_gc[cb * 96 + 64 + cu]; }
-                    fpos += 1;
-                    if (cu == 0) { seg_st[cb * 8 + 5] = fpos; seg_st[cb * 8 + 6] = fidx; }
-                    const float gr = first ? 0.f : gsum[cb * 96 + cu], gz = first ? 0.f : gsum[cb * 96 + UPB + cu],
-                                gn = first ? 0.f : gsum[cb * 96 + 2 * UPB + cu];
-                    hold = first ? 0.f : c_hold[cb * 32 + cu];
-                    s0 = gr + bq0; s1 = gz + bq1; sn = gn + bq2;
-                }
+            float s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
+            if (st_active && !st_first) {                                // gsum of step t-1 is complete: barrier B
+                s0 = gsum[cb * 96 + cu]; s1 = gsum[cb * 96 + UPB + cu]; sn = gsum[cb * 96 + 2 * UPB + cu];
+                hold = hprev;
             }
+            s0 += bq0; s1 += bq1; sn += bq2;
             // ---- x_{t-1}
             int x = NC / 2;
             if (want_x) {
@@ -499,39 +552,29 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 x = lane < 32 ? x0 : x1;
             }
             XD_STAMP(11, 1);
-            // ---- the x-dependent rest: sample out, embedding row, gates, publish h_t
+            // ---- embedding row, gates, publish h_t
             if (cell_on) {
-                if (emit_at >= 0 && cu == 0 && rank == (cb & 31)) {      // network_vocoder.py:78 output
-                    if (p.wav) p.wav[(size_t)emit_row * p.Lout + emit_at] = mtab[x];
-                    if (p.mulaw) p.mulaw[(size_t)emit_row * p.Lout + emit_at] = x;
-                }
                 float hn = 0.f;
-                if (active && cu < UPB) {
-                    const int xe = first ? NC / 2 : x;
+                if (st_active && cu < UPB) {
+                    const int xe = st_first ? NC / 2 : x;
                     const float e0 = gemb[(xe * 3 + 0) * UPB + cu], e1 = gemb[(xe * 3 + 1) * UPB + cu], e2 = gemb[(xe * 3 + 2) * UPB + cu];
                     const float r = sigmoidf_((e0 + g0) + s0);
                     const float z = sigmoidf_((e1 + g1) + s1);
                     const float nn = tanhf((e2 + g2) + r * sn);
                     hn = (1.0f - z) * nn + z * hold;
-                    c_hold[cb * 32 + cu] = hn;
+                    hprev = hn;
                 }
                 if (cu < UPB) xd_put(gh, (((unsigned)(rank * BXT + cb) << 5) + cu) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
             }
             XD_STAMP(11, 2);
-            // ---- in the shadow of the h_t exchange: the noise of this step's draw (class lane & 7 of slot sv + 2 ((lane >> 3) & 1))
-            // and the first half of the fc1 weights
-            const int lt_b = __builtin_amdgcn_readlane(lt, 0), lt_b2 = __builtin_amdgcn_readlane(lt, 32);
-            const unsigned ut_b = __builtin_amdgcn_readlane(utt, 0), ut_b2 = __builtin_amdgcn_readlane(utt, 32);
-            if (lane < 16) {
-                const int which = (int)(lane >> 3), b = sv + 2 * which;
-                if (b < bx) {
-                    const unsigned cls = FPB * rank + (lane & 7u);
-                    const unsigned wd = philox_word((unsigned)(which ? lt_b2 : lt_b), which ? ut_b2 : ut_b, cls >> 2,
-                                                    (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
-                    noise[b * 8 + (lane & 7u)] = gumbel_from_word(wd);
-                }
+            // ---- in the shadow of the h_t exchange: the sample x_{t-1} goes out (network_vocoder.py:78 output), the slot's state
+            // for step t + 1, the first phase of the fc1 weights
+            if (st_emit && cu == 0 && rank == (cb & 31)) {
+                if (p.wav) p.wav[(size_t)st_erow * p.Lout + st_eidx] = mtab[x];
+                if (p.mulaw) p.mulaw[(size_t)st_erow * p.Lout + st_eidx] = x;
             }
-            float4 w1p[8];                                               // phase 0 of the fc1 weights
+            advance(t + 1);
+            float4 w1p[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) w1p[i] = wp1[i];
             XD_SWEEP_H();
@@ -556,17 +599,16 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             XD_STAMP(11, 5);
             XD_STAMP(10, 10);
-            // ---- W_hh rows 80..83 of the OTHER wave's slots (it is busier when it owns more): the first of them in the shadow
-            // of the a_t exchange (lanes 0..31; the upper half repeats them)
-            const int xb0 = 1 - sv;                                      // slots 1 - sv, 3 - sv
+            // ---- W_hh rows 80..83 of the OTHER wave's slots, in the shadow of the a_t exchange: one chain pass, the lower half
+            // wave on slot 1 - sv, the upper half on slot 3 - sv
             if (xb0 < bx) {
                 float4 wx0[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) wx0[i] = wpx[i];
                 float acc, unused;
-                chain_lds2<NT_H>(wpx, wx0, opnd + xb0 * HR, opnd + xb0 * HR, false, acc, unused);
+                chain_lds2<NT_H>(wpx, wx0, opndx, opndx, false, acc, unused);
                 const float v = chain_combine(acc);
-                if (sum_lane && lane < 32) gsum[xb0 * 96 + 80 + r8] = v;
+                if (sum_lane && (lane < 32 || x_two)) gsum[xslot * 96 + 80 + (r8 & 3u)] = v;
             }
             XD_STAMP(11, 7);
             XD_STAMP(10, 11);
@@ -575,13 +617,14 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 float4 w2p[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w2p[i] = wp2[i];
-                const float nz0 = noise[sv * 8 + r8], nz1 = noise[(sv + 2 < BXT ? sv + 2 : sv) * 8 + r8];
+                const float *nzp = noise + (t & 1) * (BXT * 8);
+                const float nz0 = nzp[sv * 8 + r8], nz1 = nzp[(sv + 2 < BXT ? sv + 2 : sv) * 8 + r8];
                 u64 va[2][4];
                 wt.start();
                 for (unsigned spins = 0;; ++spins) {
                     bool ok = true;
-                    gran_load4b<512 * BXT>(va[0], ga, ga + 128 * BXT, aoff);                            // slot sv: ranks (lane >> 3) + 8 i
-                    if (sv + 2 < bx) gran_load4b<512 * BXT>(va[1], ga, ga + 128 * BXT, aoff + 128u);    // slot sv + 2
+                    if (sv + 2 < bx) gran_load8b<512 * BXT>(va, ga, ga + 128 * BXT, aoff);       // slots sv, sv + 2: ranks (lane >> 3) + 8 i
+                    else gran_load4b<512 * BXT>(va[0], ga, ga + 128 * BXT, aoff);
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -621,16 +664,6 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 }
             }
             XD_STAMP(11, 9);
-            // ---- the second of the other wave's slots: in the shadow of the candidate exchange
-            if (xb0 + 2 < bx) {
-                float4 wx0[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) wx0[i] = wpx[i];
-                float acc, unused;
-                chain_lds2<NT_H>(wpx, wx0, opnd + (xb0 + 2) * HR, opnd + (xb0 + 2) * HR, false, acc, unused);
-                const float v = chain_combine(acc);
-                if (sum_lane && lane < 32) gsum[(xb0 + 2) * 96 + 80 + r8] = v;
-            }
             __builtin_amdgcn_s_setprio(0);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
             if (*s_abort) break;
