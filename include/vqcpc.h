@@ -200,6 +200,13 @@ int vqcpc_vocoder_logits(vqcpc_vocoder *voc, const int64_t *x, const int64_t *id
                          const int64_t *speaker, int B, int Tc, int Ts, float *logits,
                          void *stream);
 
+/* The wrapper's own glue alone (network_vocoder.py:73-77 / :56-66): series DEVICE (B, 2*Tc, dz + ds) = what the reference's
+ * Vocoder.generate / Vocoder.forward hand to rnnms -- [:, :, :dz] the code embedding of code t/2, [:, :, dz:] the speaker
+ * embedding.  The same kernel vqcpc_vocoder_generate / _logits / _condition run first; exposed so that it can be checked
+ * against the fixture captured from the reference (tests/golden/vocoder_glue.npz). */
+int vqcpc_vocoder_glue(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker, int B, int Tc, float *series,
+                       void *stream);
+
 /* Conditioning series after the prenet, (B, 2*Tc, 2*Hp) DEVICE -- stage-level tests. */
 int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
                             int B, int Tc, float *cond, void *stream);

@@ -17,7 +17,8 @@ import vectorquantizedcpc_amd as V
 from vectorquantizedcpc_amd import synth
 
 pytestmark = pytest.mark.gpu
-CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16", "odd_2x33", "long_1x300"]
+CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16", "odd_2x33", "long_1x300",
+         "edge_1x32", "edge_1x34", "edge_1x62", "edge_2x16"]      # edge_*: 16..31 rows, the edge of the bit-exact contract
 
 
 def sha(a):

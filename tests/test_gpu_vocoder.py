@@ -3,7 +3,8 @@
 PARITY UNPINNED for this half: the reference's arithmetic lives in the absent third-party
 `rnnms`; the oracle is this project's CPU statement of the same spec (self-oracle).
 Tolerances (fp32, different summation order than the oracle's serial chains):
-  prenet conditioning and teacher-forced logits: 2e-5 absolute;
+  prenet conditioning and teacher-forced logits: 1e-5 absolute (observed maxima on MI355X: 1.8e-7 and 1.6e-7,
+  printed by the tests);
   free-running samples: every GPU draw must be the oracle's Gumbel-max choice for the same
   history, or a class whose oracle score is within 2e-5 of the oracle's best (a rounding-level
   tie); identical sample sequences give identical waveforms (MSE 0 <= 1e-5).
@@ -40,7 +41,33 @@ def test_glue_and_prenet_condition(golden_dir):
     got = voc.condition(z.cuda(), spk.cuda()).cpu().numpy()
     for b in range(3):
         want = oracle.vocoder_condition(sd, z[b].numpy(), int(spk[b]))
-        assert np.abs(got[b] - want).max() <= 2e-5, b
+        print("prenet conditioning, max |GPU - C oracle| = %.3g" % float(np.abs(got[b] - want).max()))
+        assert np.abs(got[b] - want).max() <= 1e-5, b
+
+
+def test_hip_glue_equals_what_the_reference_hands_to_rnnms(golden_dir):
+    """tests/golden/vocoder_glue.npz was captured from the reference's own Vocoder.generate / Vocoder.forward
+    (network_vocoder.py:69-77, rnnms replaced by a capture stub): the HIP glue kernel must reproduce it bit for bit."""
+    voc, _ = vocoder()
+    g = np.load(os.path.join(golden_dir, "vocoder_glue.npz"))
+    got = voc.glue(torch.from_numpy(g["z"]).cuda(), torch.from_numpy(g["speaker"]).cuda()).cpu().numpy()
+    assert got.shape == g["series"].shape and np.array_equal(got, g["series"])
+
+
+def test_mulaw_table_equals_the_reference_decode(golden_dir):
+    """The waveform value of every class is the fp32 rounding of the reference's own mulaw_decode(2x/255 - 1, 256)
+    (tests/golden/preprocess.npz, made from preprocess.py:30-35): checked on the samples a decode call emits."""
+    voc, _ = vocoder()
+    dec = np.load(os.path.join(golden_dir, "preprocess.npz"))["mulaw_decode_256"].astype(np.float32)
+    z = synth.randint("mt/z", (4, 8), 512).cuda()
+    spk = synth.randint("mt/spk", (4,), 102).cuda()
+    for xcd in (0, 1):
+        voc.set_option("xcd", xcd)
+        wav, mu = voc.generate(z, spk, seed=21, utt_base=0, return_mulaw=True)
+        wav, mu = wav.cpu().numpy(), mu.cpu().numpy()
+        assert np.array_equal(wav, dec[mu])
+        assert len(np.unique(mu)) > 200                       # most of the 256 classes occur in 10 240 samples
+    voc.set_option("xcd", 0)
 
 
 def test_teacher_forced_logits():
@@ -56,7 +83,8 @@ def test_teacher_forced_logits():
     for b in range(B):
         r = oracle.vocoder_generate(sd, z[b].numpy(), int(spk[b]), seed=0, n_steps=Ts, inputs=x[b].numpy(), want_logits=True)
         worst = max(worst, float(np.abs(got[b] - r["logits"]).max()))
-    assert worst <= 2e-5, worst
+    print("teacher-forced logits, max |GPU - C oracle| = %.3g" % worst)
+    assert worst <= 1e-5, worst
 
 
 def _check_free_run(voc, sd, z, spk, n_codes, seed, utt_base, steps):
@@ -330,7 +358,7 @@ def test_configs3_shard_full_size_properties():
 def test_teacher_forced_scan_chunks_and_training_shape():
     """Vocoder.forward as a fused scan: GRU steps only, fc1 / fc2 as chunked GEMMs.  Chunk sizes that
     split Ts differently (one replay per chunk: 160 steps, last chunk partial) give the same bits; a batch that takes
-    the large-batch GRU kernel agrees with the two-tile kernel's rows; all within 2e-5 of the oracle."""
+    the large-batch GRU kernel agrees with the two-tile kernel's rows; all within 1e-5 of the oracle."""
     voc, sd = vocoder()
     B, Tc, Ts = 3, 3, 700
     z = synth.randint("tf2/z", (B, Tc), 512)
@@ -347,7 +375,9 @@ def test_teacher_forced_scan_chunks_and_training_shape():
         voc.set_option("tf_chunk_replays", 4)
     assert torch.equal(a, b) and torch.equal(a, c)
     r = oracle.vocoder_generate(sd, z[1].numpy(), int(spk[1]), seed=0, n_steps=Ts, inputs=x[1].numpy(), want_logits=True)
-    assert float(np.abs(a[1].cpu().numpy() - r["logits"]).max()) <= 2e-5
+    worst = float(np.abs(a[1].cpu().numpy() - r["logits"]).max())
+    print("teacher-forced scan (3, 700), max |GPU - C oracle| = %.3g" % worst)
+    assert worst <= 1e-5
     # 100 utterances (7 tiles -> large-batch kernel), short: rows 0..2 are the same utterances as above
     B2 = 100
     z2 = torch.cat([z, synth.randint("tf2/z2", (B2 - B, Tc), 512)])

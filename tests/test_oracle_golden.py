@@ -15,7 +15,8 @@ import pytest
 import oracle
 from vectorquantizedcpc_amd import synth
 
-CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16", "odd_2x33", "long_1x300"]
+CASES = ["c1_init", "c2_init", "c2_random_data", "ragged_3x32", "tiny_1x16", "odd_2x33", "long_1x300",
+         "edge_1x32", "edge_1x34", "edge_1x62", "edge_2x16"]      # edge_*: 16..31 rows, the edge of the bit-exact contract
 _cache = {}
 
 
@@ -127,6 +128,27 @@ def test_sampling_noise_is_finite_for_every_word():
     assert float(u_max) == 1.0 - 2.0 ** -24 and float(u_min) == 2.0 ** -24
     assert c[0] < -2.5 and 16.0 < c[-1] < 17.0               # -log(-log(2^-24)) = -2.81, -log(-log(1 - 2^-24)) = 16.6
     assert np.all(np.diff(c) >= 0)                           # monotone in the word
+
+
+def test_preprocess_functions_match_the_reference(golden_dir):
+    """preprocess.npz = outputs of the reference's OWN preemphasis / mulaw_encode / mulaw_decode (preprocess.py:16-35,
+    tools/gen_golden.py::preprocess_fixture_from_reference): the oracle's mu-law table, the package's numpy drop-ins and the
+    oracle's pre-emphasis stage (first stage of wave_to_mel) are checked against them, not against a restated formula."""
+    from oracle import mel_ref
+    from vectorquantizedcpc_amd import preprocess as pp
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    assert "reference preprocess.py" in str(g["source"])
+    dec = g["mulaw_decode_256"]
+    assert dec.dtype == np.float64 and dec.shape == (256,)
+    got = np.array([oracle.mulaw_decode(int(v)) for v in range(256)])
+    assert np.array_equal(got, dec.astype(np.float32))             # the sample loop emits the fp32 rounding of the reference's fp64
+    y = 2.0 * np.arange(256) / 255.0 - 1.0
+    assert np.array_equal(pp.mulaw_decode(y, 256), dec)
+    assert np.array_equal(pp.mulaw_encode(g["mulaw_encode_in"], 256), g["mulaw_encode_out"])
+    assert np.array_equal(pp.mulaw_encode(g["mulaw_encode_in"].astype(np.float32), 256), g["mulaw_encode_out_f32_in"])
+    assert g["mulaw_encode_out"].min() == 0 and g["mulaw_encode_out"].max() == 255
+    pre = mel_ref.preemphasis(g["preemph_in"].astype(np.float64), 0.97)
+    assert np.abs(pre - g["preemph_out"]).max() <= 1e-12           # scipy.signal.lfilter([1, -a], [1]) in float64
 
 
 def test_mulaw_decode_matches_reference_formula():

@@ -14,8 +14,9 @@ Vocoder half: the reference's arithmetic (third-party ``rnnms``) is absent.  The
 glue (``network_vocoder.py:41-78``: embed, x2 nearest upsample, speaker broadcast, concat) IS
 importable once ``rnnms.networks.vocoder`` is replaced by an in-process capture stub:
 ``vocoder_glue.npz`` records what the reference's ``Vocoder.generate`` / ``Vocoder.forward`` hand to
-``rnnms`` -- that pins the glue (a-9) by the reference, nothing more.  ``vocoder_selforacle.npz``
-comes from this project's own CPU oracle (``tests/golden/make_vocoder_fixtures.py``): self-oracle,
+``rnnms`` -- that pins the glue (a-9) by the reference, nothing more.
+``preprocess.npz``: the reference's own ``preemphasis`` / ``mulaw_encode`` / ``mulaw_decode`` (``preprocess.py:16-35``).
+``vocoder_selforacle.npz`` comes from this project's own CPU oracle (``tests/golden/make_vocoder_fixtures.py``): self-oracle,
 parity unpinned.
 
 Usage:  python tools/gen_golden.py            (writes tests/golden/)
@@ -43,6 +44,11 @@ ENCODER_CASES = {
     "tiny_1x16": (1, 16, "init", "init"),         # 8 rows: reference takes MKL's small-M path
     "odd_2x33": (2, 33, "random", "data"),        # odd T: floor((T-2)/2)+1 = 16 frames each, last frame used
     "long_1x300": (1, 300, "init", "init"),       # B = 1 but 80*T > 20480: ATen switches to oneDNN
+    # the edge of the bit-exact contract (>= 16 output rows): encode.py:42-46 is batch 1, so 0.32-0.62 s utterances live here
+    "edge_1x32": (1, 32, "init", "init"),         # 16 rows: the smallest call the contract covers
+    "edge_1x34": (1, 34, "random", "data"),       # 17 rows: one row past a whole 16-row tile
+    "edge_1x62": (1, 62, "init", "data"),         # 31 rows
+    "edge_2x16": (2, 16, "random", "init"),       # 2 x 8 = 16 rows from a batched call (oneDNN conv order)
 }
 
 
@@ -153,6 +159,30 @@ def glue_fixture_from_reference():
     print("vocoder_glue: reference Vocoder.generate/forward hand rnnms a", tuple(series.shape), "series; forward passes x through")
 
 
+def preprocess_fixture_from_reference():
+    """The reference's own ``preprocess.py`` functions that sit on the path (``:16-17`` pre-emphasis = the first stage of
+    ``wave_to_mel``; ``:20-35`` mu-law encode / decode = the last step of the sample loop).  The module imports ``librosa`` at
+    the top (absent offline); none of these three functions uses it, so an empty in-process module stands in for the name."""
+    for name in ("librosa",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import scipy.signal  # noqa: F401  (preprocess.py:17 calls scipy.signal.lfilter through `import scipy`)
+    import preprocess as pp                                    # /root/reference
+    cls = np.arange(256)
+    y = 2.0 * cls / 255.0 - 1.0
+    dec = pp.mulaw_decode(y, 256)                              # what the sample loop emits for class x: mulaw_decode(2x/255 - 1)
+    x = np.asarray(synth.uniform01("pp/x", 2048, synth.SEED), np.float64) * 2.0 - 1.0
+    x[:4] = (-1.0, 1.0, 0.0, -0.0)
+    enc = pp.mulaw_encode(x, 256)
+    x32 = x.astype(np.float32)
+    enc32 = pp.mulaw_encode(x32, 256)
+    sig = (np.asarray(synth.uniform01("pp/sig", 4096, synth.SEED), np.float64) * 2.0 - 1.0).astype(np.float32)
+    pre = pp.preemphasis(sig, 0.97)
+    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), mulaw_decode_256=dec, mulaw_encode_in=x, mulaw_encode_out=enc,
+                        mulaw_encode_out_f32_in=enc32, preemph_in=sig, preemph_out=pre,
+                        source=np.array("reference preprocess.py preemphasis / mulaw_encode / mulaw_decode (librosa replaced by an empty module)"))
+    print("preprocess: mulaw_decode", dec.dtype, dec[:2], dec[-2:], "| mulaw_encode range", enc.min(), enc.max(), "| preemphasis", pre.dtype, pre.shape)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     model = import_reference()
@@ -161,6 +191,7 @@ def main():
     for name, args in ENCODER_CASES.items():
         encoder_fixture(model, name, *args)
     glue_fixture_from_reference()
+    preprocess_fixture_from_reference()
     print("wrote", sorted(os.listdir(GOLD)))
 
 

@@ -16,7 +16,7 @@ SYMBOLS = [
     "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage", "vqcpc_encoder_vq_encode", "vqcpc_encoder_set_option",
     "vqcpc_encoder_check", "vqcpc_vocoder_check", "vqcpc_vocoder_last_path",
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
-    "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_set_option",
+    "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_glue", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
     "vqcpc_melfront_create", "vqcpc_melfront_destroy", "vqcpc_melfront_frames", "vqcpc_melfront_run",
     "vqcpc_loudness_create", "vqcpc_loudness_destroy", "vqcpc_loudness_blocks", "vqcpc_loudness_integrated",
@@ -82,6 +82,7 @@ def load():
                                            C.POINTER(C.c_uint32), vp, i64p, i32, vp]
     lib.vqcpc_vocoder_logits.argtypes = [vp, i64p, i64p, i64p, i32, i32, i32, vp, vp]
     lib.vqcpc_vocoder_condition.argtypes = [vp, i64p, i64p, i32, i32, vp, vp]
+    lib.vqcpc_vocoder_glue.argtypes = [vp, i64p, i64p, i32, i32, vp, vp]
     lib.vqcpc_vocoder_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.vqcpc_vocoder_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.vqcpc_vocoder_kernel_times.argtypes = [vp, i32, C.POINTER(C.c_float), vp]

@@ -2412,6 +2412,17 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     return VQCPC_OK;
 }
 
+extern "C" int vqcpc_vocoder_glue(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc, float *series,
+                                  void *stream) {
+    VQ_REQUIRE(v && idx && speaker && series && B > 0 && Tc > 0, "vqcpc_vocoder_glue: bad argument");
+    const auto &d = v->d;
+    const size_t ng = (size_t)B * 2 * Tc * (d.dz + d.ds);
+    hipLaunchKernelGGL(glue_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, speaker, v->code_emb,
+                       v->spk_emb, series, B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}
+
 extern "C" int vqcpc_vocoder_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc,
                                        float *cond, void *stream) {
     VQ_REQUIRE(v && idx && speaker && cond && B > 0 && Tc > 0, "vqcpc_vocoder_condition: bad argument");

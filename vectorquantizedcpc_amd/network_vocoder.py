@@ -265,6 +265,17 @@ class Vocoder(nn.Module):
         return logits
 
     @torch.no_grad()
+    def glue(self, z: Tensor, speaker: Tensor) -> Tensor:
+        """What ``network_vocoder.py:69-77`` hands to ``rnnms``: (B, 2T', dim_i_embedding + dim_speaker_embedding)."""
+        z, speaker = self._prep(z, speaker)
+        B, Tc = z.shape
+        out = torch.empty(B, 2 * Tc, self.conf.dim_i_embedding + self.conf.dim_speaker_embedding, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.load().vqcpc_vocoder_glue(self._native(), z.data_ptr(), speaker.data_ptr(), B, Tc, out.data_ptr(),
+                                                      _lib.current_stream()))
+        return out
+
+    @torch.no_grad()
     def condition(self, z: Tensor, speaker: Tensor) -> Tensor:
         """PreNet output (B, 2T', dim_voc_latent) -- stage-level checks."""
         z, speaker = self._prep(z, speaker)
