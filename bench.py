@@ -344,11 +344,9 @@ def gru_roofline(voc, n_utt, step_us, n_steps=0):
     names = {0: "ar_gru_kernel<14,1> (one tile)", 1: "ar_gru_kernel<14,2> (two tiles per workgroup)",
              2: "ar_gru_big_kernel<14> (LDS-staged state, full 16-row gate tiles)",
              4: "ar_gru_kernel<14,.,.,fused> (ONE launch: fc2 + draw of sample t-1 in front of the GRU step of sample t)",
-             5: "ar_gru_big_kernel<14,fused> (ONE launch: fc2 + draw of sample t-1 in front of the large-batch GRU step of sample t)",
-             6: "ar_gru_kernel<14,.,.,2> (the whole sample step in ONE launch: fc1 and fc2 + draw of sample t-1 in front of the GRU step of sample t)",
-             7: "ar_gru_big_kernel<14,2> (the whole sample step in ONE launch, large-batch GRU kernel)"}
-    fused = int(kind) in (4, 5, 6, 7)
-    whole = int(kind) in (6, 7)
+             5: "ar_gru_big_kernel<14,fused> (ONE launch: fc2 + draw of sample t-1 in front of the large-batch GRU step of sample t)"}
+    fused = int(kind) in (4, 5)
+    whole = False
     flop = 2.0 * (GRU_MAC + (65536 if fused else 0) + (229376 if whole else 0)) * per_launch
     achieved = flop / (gru_us * 1e-6) / 1e12
     # algorithmic bytes of one GRU-step launch: W_hh once + state in/out + gate inputs per utterance

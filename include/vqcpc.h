@@ -59,7 +59,7 @@ int vqcpc_device_count(void);
  * out_bias (z_dim); codebook (n_embeddings, z_dim) = codebook.embedding;
  * rnn_* = nn.LSTM(z_dim, c_dim) parameters (4*c_dim rows, gate order i,f,g,o).
  * Supported: in_channels % 16 == 0 (<= 256), channels == 512, z_dim == 64,
- * n_embeddings % 64 == 0 (<= 4096), c_dim % 64 == 0 (<= 1024). */
+ * n_embeddings % 64 == 0 (<= 4096), c_dim 64, 128, 256 (the reference's) or 512. */
 typedef struct {
     const float *conv_weight;
     const float *ln_weight[5];
@@ -154,8 +154,10 @@ int vqcpc_encoder_context(vqcpc_encoder *enc, const float *z, int B, int Tz, flo
  * prenet: 2-layer bidirectional nn.GRU(dz+ds -> Hp), index [layer][direction];
  * ar: embedding (n_cls, de); nn.GRU(de + 2*Hp -> Hr) single layer, gate order r,z,n;
  * fc1 (Hf, Hr) + ReLU; fc2 (n_cls, Hf).
- * Supported: dz + ds and 2*Hp multiples of 16; Hp % 4 == 0; Hr % 16 == 0, Hr % 4 == 0;
- * Hf % 16 == 0; n_cls == 256 (bits == 8); de % 4 == 0. */
+ * Supported: (dz + ds) % 32 == 0; Hp 64, 128 (the reference's), 256 or 512; Hr 512, 896 (the reference's) or 1024;
+ * de % 32 == 0; Hf 256 (the reference's), 512, 768 or 1024; bits_mu_law 8 (the reference's), 9 or 10 with n_cls = 2^bits.
+ * The resident decoders (`xcd`, `persistent`) exist for the reference's sizes (896 / 256 / 8 bits); other sizes run on the
+ * launch-per-step kernels. */
 typedef struct {
     const float *code_embedding;      /* (n_codes, dz)           */
     const float *speaker_embedding;   /* (n_speakers, ds)        */
@@ -220,9 +222,6 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * and the GRU step of sample t share ONE launch -- W_hh h does not depend on the drawn sample, so it runs while the fc2
  * workgroups of the same launch produce the candidates, which the GRU's gate waves then pick up through 8-byte granules.
  * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) aborts like `persistent`.
- * fuse_fc1 (default 0, needs fuse_fc2): fc1 of sample t-1 rides in the same launch as well -- it reads the state the
- * previous launch wrote and hands its outputs to the fc2 teams as granules: ONE launch per sample.  Same bits, but
- * measured slower than two launches at every batch size (the hand-off is 32 KB per fc2 team), so it is off.
  * xcd (default -1 = auto, 0 never, 1 whenever the dimensions are the reference's): generate() runs as EIGHT resident,
  * weight-stationary decoders, one per XCD (ar_xcd.hip): decode slot s lives on XCD s % 8; each XCD keeps a full copy of the
  * recurrent weights on its 32 CUs (W_hh in VGPRs, fc1 / fc2 / the sample-embedding table in LDS) and exchanges h_t, a_t and
@@ -320,8 +319,8 @@ int vqcpc_loudness_normalize(vqcpc_loudness *m, float *wav, const int *lens, int
  * `stream`; synchronises it).  out_us[5] = {GRU step, fc1, fc2 + draw, decode slots one launch
  * covers (a call of 33..80 or >= 192 utterances runs as two independent tile groups), which GRU-step
  * kernel that is: 0 = one tile, 1 = two tiles per workgroup, 2 = LDS-staged large-batch kernel; 4 / 5 = the fused launch
- * (fc2 + draw of the previous sample in front of the GRU step) on the small / the large-batch kernel; 6 / 7 = the whole
- * sample step in one launch (fc1 too) -- out_us[1] / out_us[2] are then fc1 / fc2 as launches of their own, for reference}.
+ * (fc2 + draw of the previous sample in front of the GRU step) on the small / the large-batch kernel -- out_us[2] is then
+ * fc2 as a launch of its own, for reference}.
  * Each time includes this chip's ~1.5 us dependent-launch boundary. */
 int vqcpc_vocoder_kernel_times(vqcpc_vocoder *voc, int reps, float *out_us, void *stream);
 

@@ -415,10 +415,10 @@ def test_persistent_single_utterance_decoder():
 
 
 def test_fused_fc2_gru_launch_same_bits_and_direct_oracle():
-    """Two launches per sample (default: fc2 + draw of sample t-1 ride in front of the GRU step of sample t and hand the
-    candidates over in-kernel), one launch (fc1 rides along too, handing a_{t-1} to the fc2 teams: measured slower, off by
-    default) and round 1's three launches give the same bits at one tile, two tiles, three tiles, on the large-batch kernel and with continuous batching (slots reused by
-    successive utterances); the default path is checked against the oracles directly in
+    """Two launches per sample (the launch path's default: fc2 + draw of sample t-1 ride in front of the GRU step of sample t
+    and hand the candidates over in-kernel) and round 1's three launches give the same bits at one tile, two tiles, three
+    tiles, on the large-batch kernel and with continuous batching (slots reused by successive utterances); the fused path is
+    checked against the oracles directly in
     test_bench_kernel_32_utterances_direct_oracle / test_large_batch_kernel_96_utterances_direct_oracle."""
     voc, _ = vocoder()
     for B, slots in ((5, 0), (32, 0), (48, 0), (40, 20), (100, 0)):
@@ -428,13 +428,11 @@ def test_fused_fc2_gru_launch_same_bits_and_direct_oracle():
         ids = list(range(500, 500 + B))
         outs = []
         try:
-            for f1, f2 in ((1, 1), (0, 1), (0, 0)):
-                voc.set_option("fuse_fc1", f1)
+            for f2 in (1, 0):
                 voc.set_option("fuse_fc2", f2)
                 voc.set_option("slots", slots)
                 outs.append(voc.generate(z, spk, n_codes=n_codes, seed=77, utt_ids=ids, return_mulaw=True))
         finally:
-            voc.set_option("fuse_fc1", 0)
             voc.set_option("fuse_fc2", 1)
             voc.set_option("slots", 0)
         for o in outs[1:]:
@@ -443,3 +441,62 @@ def test_fused_fc2_gru_launch_same_bits_and_direct_oracle():
     z = synth.randint("fz/one", (32, 2), 512).cuda()
     voc.generate(z, (torch.arange(32) % 102).cuda(), seed=1, utt_base=0, max_steps=64)
     assert voc.kernel_times(20)[4] == 4.0                   # the default path at 32 utterances is the fused fc2 || GRU launch
+
+
+def test_other_sizes_9_bit_mulaw_wider_fc_smaller_rnn():
+    """config.py:15 / :69 / :76-77 make bits_mu_law, size_h_rnn and size_h_fc configurable: 9-bit mu-law (512 classes = 32
+    candidate row groups), size_h_fc 512 (two blocks of four super-steps per fc2 wave) and size_h_rnn 512 on the
+    launch-per-step kernels (the resident decoders exist for the reference's sizes only) -- teacher-forced logits and
+    free-running draws against the C oracle, fused and three-launch schedules the same bits, large-batch kernel rows equal."""
+    sd = synth.vocoder_state_dict(size_h_rnn=512, size_h_fc=512, bits_mu_law=9)
+    conf = V.ConfVocoder()
+    conf.rnnms.bits_mu_law = 9
+    conf.rnnms.wave_ar.size_h_rnn = 512
+    conf.rnnms.wave_ar.size_h_fc = 512
+    voc = V.Vocoder(conf)
+    voc.load_state_dict(sd)
+    voc = voc.to("cuda").eval()
+    B, Tc, Ts = 3, 2, 300
+    z = synth.randint("sz/z", (B, Tc), 512)
+    spk = synth.randint("sz/spk", (B,), 102)
+    x = synth.randint("sz/x", (B, Ts), 512)
+    got = voc(x.cuda(), z.cuda(), spk.cuda()).cpu().numpy()
+    assert got.shape == (B, Ts, 512)
+    worst = 0.0
+    for b in range(B):
+        r = oracle.vocoder_generate(sd, z[b].numpy(), int(spk[b]), seed=0, n_steps=Ts, inputs=x[b].numpy(), want_logits=True, bits=9)
+        worst = max(worst, float(np.abs(got[b] - r["logits"]).max()))
+    print("9-bit / 512 / 512 teacher-forced logits, max |GPU - C oracle| = %.3g" % worst)
+    assert worst <= 1e-5
+    outs = []
+    for f2 in (1, 0):
+        voc.set_option("fuse_fc2", f2)
+        wav, mu = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=40, return_mulaw=True, max_steps=Ts)
+        voc.check()
+        assert voc.last_path() == 0
+        outs.append((wav.cpu().numpy(), mu.cpu().numpy()))
+    voc.set_option("fuse_fc2", 1)
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0])
+    wav, mu = outs[0]
+    assert mu.max() > 255                                     # classes beyond 8 bits do occur
+    for b in range(B):
+        s_gpu = mu[b, :Ts]
+        inputs = np.concatenate([[256], s_gpu[:-1]])
+        r = oracle.vocoder_generate(sd, z[b].numpy(), int(spk[b]), seed=13, utterance=40 + b, n_steps=Ts, inputs=inputs,
+                                    want_logits=True, bits=9)
+        for t in np.nonzero(r["samples"] != s_gpu)[0]:
+            pick, sc = oracle.sample_from_logits(r["logits"][t], 13, 40 + b, int(t))
+            assert sc[pick] - sc[int(s_gpu[t])] <= 2e-5, (b, int(t))
+        assert np.array_equal(wav[b, :Ts], np.array([oracle.mulaw_decode(int(v), 9) for v in s_gpu], np.float32))
+    # 100 utterances: the large-batch kernel; rows 0..2 are the utterances above
+    z2 = torch.cat([z, synth.randint("sz/z2", (97, Tc), 512)])
+    spk2 = torch.cat([spk, synth.randint("sz/s2", (97,), 102)])
+    w2, m2 = voc.generate(z2.cuda(), spk2.cuda(), seed=13, utt_base=40, return_mulaw=True, max_steps=Ts)
+    voc.check()
+    assert np.array_equal(m2[:B].cpu().numpy(), mu) and np.array_equal(w2[:B].cpu().numpy(), wav)
+    with pytest.raises(RuntimeError):                         # a size outside the built list is an explicit error
+        bad = V.ConfVocoder()
+        bad.rnnms.wave_ar.size_h_rnn = 640
+        vb = V.Vocoder(bad)
+        vb.load_state_dict(synth.vocoder_state_dict(size_h_rnn=640))
+        vb.to("cuda").eval().generate(z.cuda(), spk.cuda(), seed=1, utt_base=0, max_steps=8)

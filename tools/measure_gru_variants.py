@@ -22,7 +22,7 @@ print("utterances,variant,gru_us,fc1_us,fc2_us,slots_per_launch,kernel_kind,step
 for B in sizes:
     z = synth.randint("var/z", (B, 10), 512).cuda()
     spk = (torch.arange(B) % 102).cuda()
-    for name, opts in (("default", {}), ("one_launch", {"fuse_fc1": 1}), ("three_launches", {"fuse_fc2": 0}), ("one_group", {"two_groups": 0}),
+    for name, opts in (("default", {}), ("three_launches", {"fuse_fc2": 0}), ("one_group", {"two_groups": 0}),
                        ("full_tile_lds_kernel", {"big_min_tiles": 1 if B > 16 else 0, "two_groups": 0})):
         if name == "full_tile_lds_kernel" and B <= 16:
             continue
@@ -36,4 +36,3 @@ for B in sizes:
         voc.set_option("big_min_tiles", 5)
         voc.set_option("two_groups", 1)
         voc.set_option("fuse_fc2", 1)
-        voc.set_option("fuse_fc1", 0)

@@ -214,9 +214,9 @@ static int launch_seq(const SeqP &p, int step, hipStream_t s) {
     dim3 grid(p.H / 4, p.ndir, p.nbt), blk(256);
     switch (SW) {
 #define CASE(n) case n: hipLaunchKernelGGL((seq_step_kernel<G, n>), grid, blk, 0, s, p, step); break;
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+        CASE(1) CASE(2) CASE(4) CASE(8)         // hidden sizes 64, 128 (the reference's prenet), 256 (its context LSTM), 512
 #undef CASE
-        default: vq_set_error("recurrent step: hidden size %d unsupported (H/64 = %d)", p.H, SW); return VQCPC_ERR_INVALID;
+        default: vq_set_error("recurrent step: hidden size %d unsupported (64, 128, 256 and 512 are built)", p.H); return VQCPC_ERR_INVALID;
     }
     return VQCPC_OK;
 }
@@ -251,7 +251,8 @@ void vq_lstm_plan_destroy(LstmPlan *p) {
 }
 int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int D, int H,
                         LstmPlan **out) {
-    VQ_REQUIRE(D % 32 == 0 && H % 64 == 0, "LSTM: need D %% 32 == 0 and H %% 64 == 0 (got %d, %d)", D, H);
+    VQ_REQUIRE(D % 32 == 0 && (H == 64 || H == 128 || H == 256 || H == 512), "LSTM: need D %% 32 == 0 and a hidden size of 64, 128, 256 "
+               "(model.py:57) or 512 (got %d, %d)", D, H);
     LstmPlan *p = new LstmPlan();
     p->D = D; p->H = H;
     *out = p;
@@ -368,20 +369,18 @@ struct ArModel {               // constant per handle (baked into the captured g
     const float *Wf_fc1h;      // fc1 in 8-row groups (few tiles in flight: twice the workgroups, half the weight bytes each)
     float *hbuf;               // [2][nbt][Hr*16]
     float *a1;                 // [nbt][Hf*16]
-    float *cand_s;             // [Bpad][16] best score of each 16-class row group
-    int *cand_k;               // [Bpad][16] its class
+    float *cand_s;             // [Bpad][n_cls / 16] best score of each 16-class row group
+    int *cand_k;               // [Bpad][n_cls / 16] its class
     ArSlot *cur;               // [Sp] the slot row of the replay in flight (copied from ArCall::slots between
                                // replays): a fixed address, so the step kernels read it without first waiting for ArCall
-    // fused fc2 || GRU launch: candidates as 8-byte granules {(tag << 8 | class), score}, tag = step + 1, one 128-B
+    // fused fc2 || GRU launch: candidates as 8-byte granules {(tag << 10 | class), score}, tag = step + 1, one 128-B
     // line per producing workgroup: [tile][16 row groups][16 slots]
     unsigned long long *candg;
-    unsigned long long *a1g;   // fc1 outputs as {tag, value} granules in the hL layout of `a1` (fused level 2: fc1 in the launch too)
     unsigned *abort_dev;       // set when a candidate wait timed out: later steps stop waiting
     unsigned *abort_host;      // the same, host-mapped: the next call on the handle reports it
     unsigned timeout_ticks;    // bound of the in-kernel candidate waits (100 MHz ticks)
     int dbg_drop_t;            // tests: the fc2 team of row group 3, tile 0 skips its candidate publish at this step (-1: never)
-    int fused;                 // 0: three launches per sample; 1: fc2 + draw ride in the GRU launch (candidates in candg);
-                               // 2: fc1 rides along as well (its outputs in a1g): ONE launch per sample
+    int fused;                 // 0: three launches per sample; 1: fc2 + draw ride in the GRU launch (candidates in candg)
     int Hr, Hf, n_cls, upsample;
 };
 
@@ -390,15 +389,14 @@ struct ArModel {               // constant per handle (baked into the captured g
 // first-argmax, split so that the request can be issued early.  (A 4-lanes-per-slot variant that
 // combined by __shfl_xor made the wave-specialised kernel 5x slower on gfx950 -- measured, dropped.)
 struct Cand16 { float4 s[4]; int4 k[4]; };
-__device__ __forceinline__ void load_candidates16(const ArModel &m, int sg, Cand16 &cd) {
-    const float4 *ps = (const float4 *)(m.cand_s + (size_t)sg * 16);
-    const int4 *pk = (const int4 *)(m.cand_k + (size_t)sg * 16);
+__device__ __forceinline__ void load_candidates16(const ArModel &m, int sg, int c0, Cand16 &cd) {
+    const int nrg = m.n_cls >> 4;
+    const float4 *ps = (const float4 *)(m.cand_s + (size_t)sg * nrg + c0);
+    const int4 *pk = (const int4 *)(m.cand_k + (size_t)sg * nrg + c0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { cd.s[q] = ps[q]; cd.k[q] = pk[q]; }
 }
-__device__ __forceinline__ int merge_candidates16(const Cand16 &cd) {
-    float best = -INFINITY;
-    int k = 0;
+__device__ __forceinline__ void merge16(const Cand16 &cd, float &best, int &k) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (cd.s[q].x > best) { best = cd.s[q].x; k = cd.k[q].x; }
@@ -406,7 +404,56 @@ __device__ __forceinline__ int merge_candidates16(const Cand16 &cd) {
         if (cd.s[q].z > best) { best = cd.s[q].z; k = cd.k[q].z; }
         if (cd.s[q].w > best) { best = cd.s[q].w; k = cd.k[q].w; }
     }
+}
+// all n_cls / 16 candidates of the slot: the first 16 were requested early (cd), further chunks (n_cls > 256) follow
+__device__ __forceinline__ int merge_candidates(const ArModel &m, int sg, const Cand16 &cd) {
+    float best = -INFINITY;
+    int k = 0;
+    merge16(cd, best, k);
+    for (int c0 = 16; c0 < (m.n_cls >> 4); c0 += 16) {
+        Cand16 more;
+        load_candidates16(m, sg, c0, more);
+        merge16(more, best, k);
+    }
     return k;
+}
+// The same from the granules of the fused launch: wait until the slot's candidates carry step t's tag (from the fc2 workgroups
+// of THIS launch, or, at the first step of a replay, of the trailing fc2 launch of the previous one), 16 row groups at a
+// time, and take the first argmax.  Bounded; a timeout raises the abort words and returns class 0.
+#define CAND_TAG_BITS 22
+__device__ __forceinline__ int wait_candidates(const ArModel &m, int sg, int t, bool need, int lane) {
+    const int nrg = m.n_cls >> 4;
+    const unsigned tag = (unsigned)t & ((1u << CAND_TAG_BITS) - 1u);
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    bool gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    float best = -INFINITY;
+    int xf = 0;
+    for (int c0 = 0; c0 < nrg; c0 += 16) {
+        const u64 *cg = m.candg + ((size_t)(sg >> 4) * nrg + c0) * 16 + (sg & 15);
+        u64 gv[16];
+        for (unsigned spins = 0; !gave_up; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                gv[q] = ps_load(cg + q * 16);
+                ok &= (unsigned)(gv[q] >> 42) == tag;
+            }
+            if (__all(ok || !need)) break;
+            if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > (u64)m.timeout_ticks) {      // default 0.25 s
+                if (lane == 0) {
+                    __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                gave_up = true;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                               // row groups are in class order: first argmax
+            const float sq = __uint_as_float((unsigned)gv[q]);
+            if (!gave_up && sq > best) { best = sq; xf = (int)((gv[q] >> 32) & 1023u); }
+        }
+    }
+    return xf;
 }
 
 // `live` = columns (decode slots) of tile bt in use: a lane of a dead column re-reads column 0 of its k group
@@ -462,9 +509,8 @@ __device__ __forceinline__ bool handoff_timed_out(const ArModel &m, u64 t0, unsi
 }
 
 // fc1 + ReLU over ROWS rows x one utterance tile for local step `ts` (the GRU of that step has written its state).
-// GRAN = 0: outputs to the plain `a1` array (a launch of its own); GRAN = 1: as {tag, value} granules for the fc2 teams of
-// the SAME launch.  `tid` / `worker` as in fc2_body.
-template <int SW, int ROWS, int GRAN>
+// `tid` / `worker` as in fc2_body.
+template <int SW, int ROWS>
 __device__ __forceinline__ void fc1_body(const ArModel &m, const ArCall *__restrict__ cp, int ts, int rg, int bt, int nbt,
                                          float (*red)[16][17], int tid, bool worker) {
     const int lane = tid & 63, wave = (tid >> 6) & 3;
@@ -492,24 +538,26 @@ __device__ __forceinline__ void fc1_body(const ArModel &m, const ArCall *__restr
         v += bias;
         v = v > 0.f ? v : 0.f;
         const size_t at = hl_index(m.Hf, bt * 16 + bb, row);
-        if (GRAN) ps_store(m.a1g + at, ((u64)(unsigned)(c.t_base + ts + 1) << 32) | __float_as_uint(v));
-        else m.a1[at] = v;
+        m.a1[at] = v;
     }
 }
 
 // `tid` = index inside the 256-thread team that computes (rg, bt); `worker` = false for threads that only keep the
 // workgroup's barriers company (the tail of a 320/384-thread block, teams past the last (rg, bt) of a 1024-thread block).
-// A1G = 1: the fc1 outputs come as granules from fc1 teams of the SAME launch (bounded sweep until every tag is this
-// step's); the weights and the draw's noise are in registers by then.
-template <int GRANULES, int A1G>
+template <int GRANULES>
 __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restrict__ cp, int ts, int rg, int bt, int nbt,
                                          float (*red)[16][17], float (*sc)[17], int tid, bool worker) {
     const int lane = tid & 63, wave = (tid >> 6) & 3;
     const int wv = worker ? wave : 0;
     if (!worker) { rg = 0; bt = 0; }
+    // K = size_h_fc = 64 swf: this wave's quarter is swf super-steps, taken four at a time (256: once)
+    const int swf = m.Hf >> 6, nrg = m.n_cls >> 4;
+    const int live_cols = bt == nbt - 1 ? m.live_last : 16;
+    const float4 *wfp = (const float4 *)m.Wf_fc2 + ((size_t)rg * (m.Hf >> 4) + (size_t)wv * swf) * 64 + lane;
+    const float4 *hfp = (const float4 *)m.a1 + ((size_t)bt * (m.Hf >> 2)) * 16 + (size_t)wv * swf * 64 + ((lane & 15) < live_cols ? lane : (lane & 48));
     float4 wf[4], hv[4];
-    load_wfrag<4>(m.Wf_fc2, rg, 4, wv, lane, wf);
-    if (!A1G) load_hfrag<4>(m.a1, m.Hf, bt, wv, lane, bt == nbt - 1 ? m.live_last : 16, hv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { wf[q] = wfp[q * 64]; hv[q] = hfp[q * 64]; }
     const int rr = (tid >> 4) & 15, bb = tid & 15, cls = 16 * rg + rr, bg = bt * 16 + bb;      // bg = decode slot
     const float bias = m.b_fc2[cls];
     __builtin_amdgcn_sched_barrier(0);
@@ -525,35 +573,21 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
     const float g = gumbel_from_word(w);
     const bool live = ts >= 0 && t < c.max_t && sl.row >= 0 && lt >= 0 && lt < sl.len;
     __builtin_amdgcn_sched_barrier(0);
-    if (A1G) {
-        // a_t of this tile from the fc1 teams of this launch: the 16 granules behind this lane's four operand words
-        const int live_cols = bt == nbt - 1 ? m.live_last : 16;
-        const int hl = (lane & 15) < live_cols ? lane : (lane & 48);
-        const u64 *gp = m.a1g + (((size_t)bt * (m.Hf >> 2)) * 16 + (size_t)wv * 4 * 64 + hl) * 4;
-        const unsigned tag = (unsigned)(t + 1);
-        const bool need = ts >= 0 && t < c.max_t;                   // fc1 publishes exactly then (wave-uniform)
-        u64 gv[16];
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
-        bool gave_up = !need || __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        for (unsigned spins = 0; !gave_up; ++spins) {
-            bool ok = true;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0;;) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    gv[4 * s + q] = ps_load(gp + (size_t)s * 256 + q);
-                    ok &= (unsigned)(gv[4 * s + q] >> 32) == tag;
-                }
-            if (__all(ok)) break;
-            gave_up = handoff_timed_out(m, t0, spins, lane);
+        for (int q = 0; q < 4; ++q) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q].x, hv[q].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q].y, hv[q].y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q].z, hv[q].z, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q].w, hv[q].w, a1, 0, 0, 0);
         }
+        s0 += 4;
+        if (s0 >= swf) break;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            hv[s] = gave_up ? make_float4(0.f, 0.f, 0.f, 0.f)
-                            : make_float4(__uint_as_float((unsigned)gv[4 * s]), __uint_as_float((unsigned)gv[4 * s + 1]),
-                                          __uint_as_float((unsigned)gv[4 * s + 2]), __uint_as_float((unsigned)gv[4 * s + 3]));
+        for (int q = 0; q < 4; ++q) { wf[q] = wfp[(s0 + q) * 64]; hv[q] = hfp[(s0 + q) * 64]; }
     }
-    const f32x4 acc = mfma_frag<4>(wf, hv);
+    const f32x4 acc = a0 + a1;
     if (worker) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
@@ -573,38 +607,31 @@ __device__ __forceinline__ void fc2_body(const ArModel &m, const ArCall *__restr
         for (int r = 1; r < 16; ++r)
             if (sc[r][bb] > best) { best = sc[r][bb]; k = r; }
         if (GRANULES) {
-            const unsigned tag = (unsigned)(t + 1) & 0xFFFFFFu;
+            const unsigned tag = (unsigned)(t + 1) & ((1u << CAND_TAG_BITS) - 1u);
             if (!(m.dbg_drop_t >= 0 && t == m.dbg_drop_t && rg == 3 && bt == 0))
-            ps_store(m.candg + ((size_t)(bt * 16 + rg) * 16 + bb), ((u64)((tag << 8) | (unsigned)(16 * rg + k)) << 32) | __float_as_uint(best));
+            ps_store(m.candg + ((size_t)(bt * nrg + rg) * 16 + bb), ((u64)((tag << 10) | (unsigned)(16 * rg + k)) << 32) | __float_as_uint(best));
         } else {
-            m.cand_s[(size_t)bg * 16 + rg] = best;
-            m.cand_k[(size_t)bg * 16 + rg] = 16 * rg + k;
+            m.cand_s[(size_t)bg * nrg + rg] = best;
+            m.cand_k[(size_t)bg * nrg + rg] = 16 * rg + k;
         }
     }
 }
 
-// FUSED = 2: fc1 of step t-1 rides along as well -- the grid is [fc1 teams | fc2 teams | GRU workgroups], fc1 reads the state the
-// previous launch wrote, hands a_{t-1} to the fc2 teams as granules, they hand the candidates to the gate waves: ONE launch per
-// sample, two chained in-kernel hand-offs under the W_hh h MFMA phase.
 template <int SW, int NB, int LEADP, int FUSED>      // NB = utterance tiles (of 16) in flight per pass: 1 or 2
 __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt,
-                                                               int n_fc1, int n_fc2) {
+                                                               int n_fc2) {
     __shared__ float red[NB][4][16][17];
     __shared__ __attribute__((aligned(16))) float mt[256];            // mu-law decode table (row group 0 emits the samples)
     __shared__ float sc[16][17];                                       // FUSED: scores of an fc2 workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, Hr = m.Hr;
     int rg = blockIdx.x, pass = blockIdx.y;
     if (FUSED) {
-        if (FUSED == 2 && (int)blockIdx.x < n_fc1) {                   // fc1 of the PREVIOUS step: 8-row groups (<= 4 tiles)
-            fc1_body<SW, 8, 1>(m, cp, t_local - 1, blockIdx.x % (m.Hf / 8), blockIdx.x / (m.Hf / 8), nbt, red[0], tid, tid < 256);
+        if ((int)blockIdx.x < n_fc2) {                                 // fc2 + draw of the PREVIOUS step
+            const int fb = blockIdx.x, nrg = m.n_cls >> 4;
+            fc2_body<1>(m, cp, t_local - 1, fb % nrg, fb / nrg, nbt, red[0], sc, tid, tid < 256);
             return;
         }
-        if ((int)blockIdx.x < n_fc1 + n_fc2) {                         // fc2 + draw of the PREVIOUS step
-            const int fb = blockIdx.x - n_fc1;
-            fc2_body<1, FUSED == 2>(m, cp, t_local - 1, fb & 15, fb >> 4, nbt, red[0], sc, tid, tid < 256);
-            return;
-        }
-        const int gb = blockIdx.x - n_fc1 - n_fc2;
+        const int gb = blockIdx.x - n_fc2;
         rg = gb % (Hr >> 2);
         pass = gb / (Hr >> 2);
     }
@@ -688,7 +715,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             // has a fixed address is requested up front -- candidates, slot record, call record, biases, old
             // state, the slot's Gcond row of this replay (gcur) -- so that only the Gemb row is a second level.
             Cand16 cd;
-            if (!FUSED) load_candidates16(m, sg, cd);
+            if (!FUSED) load_candidates16(m, sg, 0, cd);
             const ArSlot sl = m.cur[sg];
             const ArCall c = *cp;
             const float4 bq = m.bh4[rg * 4 + u];
@@ -706,44 +733,13 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
             AR_STAMP(tid == 0 && (active || !active), 0, 4);
             first = lt == 0;
             int xf = 0;
-            if (FUSED) {
-                // wait for the 16 candidates of this slot (step t-1's draw, tag t) from the fc2 workgroups of THIS launch
-                // (or, at the first step of a replay, of the trailing fc2 launch of the previous one)
-                const bool need = active && !first;
-                const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
-                const unsigned tag = (unsigned)t & 0xFFFFFFu;
-                u64 gv[16];
-                const u64 t0 = __builtin_amdgcn_s_memrealtime();
-                bool gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-                for (unsigned spins = 0; !gave_up; ++spins) {
-                    bool ok = true;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        gv[q] = ps_load(cg + q * 16);
-                        ok &= (unsigned)(gv[q] >> 40) == tag;
-                    }
-                    if (__all(ok || !need)) break;
-                    if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > (u64)m.timeout_ticks) {      // default 0.25 s
-                        if (lane == 0) {
-                            __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        }
-                        gave_up = true;
-                    }
-                }
-                float best = -INFINITY;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {                               // row groups are in class order: first argmax
-                    const float sq = __uint_as_float((unsigned)gv[q]);
-                    if (!gave_up && sq > best) { best = sq; xf = (int)((gv[q] >> 32) & 255u); }
-                }
-            }
+            if (FUSED) xf = wait_candidates(m, sg, t, active && !first, lane);
             if (active) {
                 int x;
                 if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
                 else if (first) x = m.n_cls / 2;
                 else {
-                    if (!FUSED) x = merge_candidates16(cd);
+                    if (!FUSED) x = merge_candidates(m, sg, cd);
                     else x = xf;
                     emit = rg == 0 && u == 0;                   // sample lt-1 goes out after the barrier
                     if (emit) { wavp = c.wav ? c.wav + (size_t)sl.row * c.Lout + lt - 1 : nullptr;
@@ -813,8 +809,7 @@ __device__ __forceinline__ void big_stage_store(float4 *dst, int t4, int tid, co
 // FUSED = 1: as in ar_gru_kernel, the first n_fc2 blocks of the launch run fc2 + draw of the PREVIOUS step and the
 // cell-update waves pick the candidates up through granules -- after the staging barriers, while the MFMA waves compute.
 template <int SW, int FUSED>
-__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc1,
-                                                          int n_fc2) {
+__global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt, int n_fc2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Hr = m.Hr;
     float4 *hs = (float4 *)smem;                                             // [2][Hr*4] float4 = two state tiles
@@ -822,22 +817,17 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int blk = blockIdx.x, passy = blockIdx.y;
     if (FUSED) {
-        // four 256-thread teams per workgroup, one (row group, tile) each: 4 nbt fc1 and 4 nbt fc2 workgroups in front of the GRU ones
+        // four 256-thread teams per workgroup, one (row group, tile) each: 4 nbt fc2 workgroups in front of the GRU ones
         const int team = tid >> 8;
         char *base = smem + (size_t)team * (5 * 16 * 17 * sizeof(float));
-        if (FUSED == 2 && (int)blockIdx.x < n_fc1) {                   // fc1 of the previous step: 16-row groups
+        if ((int)blockIdx.x < n_fc2) {
             const int pair = blockIdx.x * 4 + team;
-            fc1_body<SW, 16, 1>(m, cp, t_local - 1, pair % (m.Hf / 16), pair / (m.Hf / 16), nbt, (float (*)[16][17])base, tid & 255,
-                                pair < (m.Hf / 16) * nbt);
+            const int nrg = m.n_cls >> 4;
+            fc2_body<1>(m, cp, t_local - 1, pair % nrg, pair / nrg, nbt, (float (*)[16][17])base,
+                        (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, pair < nrg * nbt);
             return;
         }
-        if ((int)blockIdx.x < n_fc1 + n_fc2) {
-            const int pair = (blockIdx.x - n_fc1) * 4 + team;
-            fc2_body<1, FUSED == 2>(m, cp, t_local - 1, pair & 15, pair >> 4, nbt, (float (*)[16][17])base,
-                                    (float (*)[17])(base + 4 * 16 * 17 * sizeof(float)), tid & 255, pair < 16 * nbt);
-            return;
-        }
-        const int gb = blockIdx.x - n_fc1 - n_fc2;
+        const int gb = blockIdx.x - n_fc2;
         blk = gb % (Hr >> 4);
         passy = gb / (Hr >> 4);
     }
@@ -860,7 +850,7 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
         float *hallp = nullptr;
         // first level of the operand chain: everything with a fixed address (as in ar_gru_kernel)
         Cand16 cd;
-        if (!FUSED) load_candidates16(m, sg, cd);
+        if (!FUSED) load_candidates16(m, sg, 0, cd);
         const ArSlot sl = m.cur[sg];
         const ArCall c = *cp;
 #pragma unroll
@@ -888,41 +878,14 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
             big_stage_load(src + t4, t4, tid, nb > 1, st);
             big_stage_store(hs + t4, t4, tid, st);
             __syncthreads();
-            const bool need = active && !first;
-            const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
-            const unsigned tag = (unsigned)t & 0xFFFFFFu;
-            u64 gv[16];
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
-            bool gave_up = __hip_atomic_load(m.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-            for (unsigned spins = 0; !gave_up; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int qq = 0; qq < 16; ++qq) {
-                    gv[qq] = ps_load(cg + qq * 16);
-                    ok &= (unsigned)(gv[qq] >> 40) == tag;
-                }
-                if (__all(ok || !need)) break;
-                if ((spins & 255) == 255 && __builtin_amdgcn_s_memrealtime() - t0 > (u64)m.timeout_ticks) {      // default 0.25 s
-                    if (lane == 0) {
-                        __hip_atomic_store(m.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(m.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                    gave_up = true;
-                }
-            }
-            float best = -INFINITY;
-#pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-                const float sq = __uint_as_float((unsigned)gv[qq]);
-                if (!gave_up && sq > best) { best = sq; xf = (int)((gv[qq] >> 32) & 255u); }
-            }
+            xf = wait_candidates(m, sg, t, active && !first, lane);
         }
         if (active) {
             int x;
             if (c.inputs) x = (int)c.inputs[(size_t)sl.row * c.Ts + lt];
             else if (first) x = m.n_cls / 2;
             else {
-                x = FUSED ? xf : merge_candidates16(cd);
+                x = FUSED ? xf : merge_candidates(m, sg, cd);
                 if (blk == 0 && uh == 0 && u == 0) {             // emit sample lt-1 (network_vocoder.py:78 output)
                     if (c.wav) c.wav[(size_t)sl.row * c.Lout + lt - 1] = m.mulaw_tab[x];
                     if (c.mulaw) c.mulaw[(size_t)sl.row * c.Lout + lt - 1] = x;
@@ -1007,19 +970,8 @@ template <int SW, int ROWS>
 __global__ __launch_bounds__(256) void ar_fc1_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
     __shared__ float red[4][16][17];
     AR_STAMP(threadIdx.x == 0, 1, 0);
-    fc1_body<SW, ROWS, 0>(m, cp, t_local, blockIdx.x, blockIdx.y, nbt, red, threadIdx.x, true);
+    fc1_body<SW, ROWS>(m, cp, t_local, blockIdx.x, blockIdx.y, nbt, red, threadIdx.x, true);
     AR_STAMP(threadIdx.x == 0, 1, 3);
-}
-
-// Trailing launch of a fully fused replay: fc1 and fc2 + draw of the replay's LAST sample (no GRU step follows inside the
-// replay); fc1 teams first, the fc2 teams wait for them through the granules.  Grid = (Hf / ROWS) * nbt + 16 * nbt blocks.
-template <int SW, int ROWS>
-__global__ __launch_bounds__(256) void ar_fc12_kernel(ArModel m, const ArCall *__restrict__ cp, int t_local, int nbt) {
-    __shared__ float red[4][16][17];
-    __shared__ float sc[16][17];
-    const int n1 = (m.Hf / ROWS) * nbt;
-    if ((int)blockIdx.x < n1) fc1_body<SW, ROWS, 1>(m, cp, t_local, blockIdx.x % (m.Hf / ROWS), blockIdx.x / (m.Hf / ROWS), nbt, red, threadIdx.x, true);
-    else fc2_body<1, 1>(m, cp, t_local, (blockIdx.x - n1) & 15, (blockIdx.x - n1) >> 4, nbt, red, sc, threadIdx.x, true);
 }
 
 // fc2 + draw as a launch of its own (plain candidate arrays; GRANULES = 1: the trailing launch of a fused replay).
@@ -1028,7 +980,7 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
     __shared__ float red[4][16][17];
     __shared__ float sc[16][17];
     AR_STAMP(threadIdx.x == 0, 2, 0);
-    fc2_body<GRANULES, 0>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc, threadIdx.x, true);
+    fc2_body<GRANULES>(m, cp, t_local, blockIdx.x, blockIdx.y, gridDim.y, red, sc, threadIdx.x, true);
     AR_STAMP(threadIdx.x == 0, 2, 3);
 }
 
@@ -1522,22 +1474,23 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
     if (end <= c.t_base || end > c.t_base + c.S) return;
     float best;
     int x;
+    const int nrg = m.n_cls >> 4;
     if (m.fused) {
-        const u64 *cg = m.candg + ((size_t)(sg >> 4) * 16) * 16 + (sg & 15);
+        const u64 *cg = m.candg + ((size_t)(sg >> 4) * nrg) * 16 + (sg & 15);
         u64 gq = ps_load(cg);
         best = __uint_as_float((unsigned)gq);
-        x = (int)((gq >> 32) & 255u);
-        for (int q = 1; q < 16; ++q) {
+        x = (int)((gq >> 32) & 1023u);
+        for (int q = 1; q < nrg; ++q) {
             gq = ps_load(cg + q * 16);
             const float sc = __uint_as_float((unsigned)gq);
-            if (sc > best) { best = sc; x = (int)((gq >> 32) & 255u); }
+            if (sc > best) { best = sc; x = (int)((gq >> 32) & 1023u); }
         }
     } else {
-        best = m.cand_s[(size_t)sg * 16];
-        x = m.cand_k[(size_t)sg * 16];
-        for (int q = 1; q < 16; ++q) {
-            const float sc = m.cand_s[(size_t)sg * 16 + q];
-            if (sc > best) { best = sc; x = m.cand_k[(size_t)sg * 16 + q]; }
+        best = m.cand_s[(size_t)sg * nrg];
+        x = m.cand_k[(size_t)sg * nrg];
+        for (int q = 1; q < nrg; ++q) {
+            const float sc = m.cand_s[(size_t)sg * nrg + q];
+            if (sc > best) { best = sc; x = m.cand_k[(size_t)sg * nrg + q]; }
         }
     }
     if (c.wav) c.wav[(size_t)sl.row * c.Lout + sl.len - 1] = m.mulaw_tab[x];
@@ -1629,7 +1582,7 @@ struct vqcpc_vocoder {
     // step overlaps the other's fc1/fc2; there is no edge between them inside a graph.
     struct Group {
         ArCall *call = nullptr;          // device
-        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur, candg, a1g;   // candg: candidate granules + the abort word behind them
+        DevBuf har, a1, cand_s, cand_k, slot_tab, cur, gcur, candg;   // candg: candidate granules + the abort word behind them
         std::map<int, hipGraphExec_t> graphs;   // key: (tiles in the group, live columns of the last tile, lead6)
         const void *baked[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // workspace pointers the cached graphs captured
     } grp[2];
@@ -1643,9 +1596,6 @@ struct vqcpc_vocoder {
     HostStage stage;
     float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
     int fuse_fc2 = 1;                    // fc2 + draw of step t-1 and the GRU step t share one launch
-    int fuse_fc1 = 0;                    // ... and fc1 of step t-1 as well: ONE launch per sample (needs fuse_fc2).  Measured and left
-                                         // off: the a_t hand-off is 32 KB of granules per fc2 team and the fc1 teams take CUs from the GRU
-                                         // workgroups -- 9.9 vs 9.6 us per step at 32 utterances, 19.0 vs 15.5 at 128 (r02_gru_variants.csv)
     int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
     bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
     // one resident decoder per XCD (ar_xcd.hip): -1 auto, 0 never, 1 whenever the dimensions allow
@@ -1683,7 +1633,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     for (auto &g : v->grp) {
         for (auto &kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
         if (g.call) (void)hipFree(g.call);
-        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur, &g.candg, &g.a1g};
+        DevBuf *gb[] = {&g.har, &g.a1, &g.cand_s, &g.cand_k, &g.slot_tab, &g.cur, &g.gcur, &g.candg};
         for (DevBuf *b : gb) b->release();
     }
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
@@ -1786,10 +1736,15 @@ extern "C" int vqcpc_vocoder_create(const vqcpc_vocoder_weights *w, vqcpc_vocode
     VQ_REQUIRE(w && out, "vqcpc_vocoder_create: null argument");
     *out = nullptr;
     TRY(vq_require_gfx950());
-    VQ_REQUIRE(w->n_cls == 256 && w->bits_mu_law == 8, "vocoder: n_cls must be 256 (bits_mu_law 8)");
-    VQ_REQUIRE(w->Hf == 256, "vocoder: size_h_fc must be 256 (got %d)", w->Hf);
+    VQ_REQUIRE(w->bits_mu_law >= 8 && w->bits_mu_law <= 10 && w->n_cls == (1 << w->bits_mu_law),
+               "vocoder: bits_mu_law must be 8 (config.py:15), 9 or 10 with n_cls = 2^bits (got %d, %d)", w->bits_mu_law, w->n_cls);
+    VQ_REQUIRE(w->Hf >= 256 && w->Hf <= 1024 && w->Hf % 256 == 0, "vocoder: size_h_fc must be 256 (config.py:77), 512, 768 or 1024 (got %d)", w->Hf);
     VQ_REQUIRE((w->dz + w->ds) % 32 == 0 && w->Hp % 64 == 0 && w->Hp <= 1024, "vocoder: dz+ds %% 32 and Hp %% 64 required");
-    VQ_REQUIRE(w->Hr % 64 == 0 && w->Hr <= 1024 && w->de % 32 == 0, "vocoder: Hr %% 64 and de %% 32 required (got %d, %d)", w->Hr, w->de);
+    VQ_REQUIRE(w->de % 32 == 0, "vocoder: size_i_embed_ar %% 32 required (got %d)", w->de);
+    VQ_REQUIRE(w->Hr == 512 || w->Hr == 896 || w->Hr == 1024, "vocoder: size_h_rnn %d: the per-sample kernels are built for 512, 896 "
+               "(config.py:76) and 1024", w->Hr);
+    VQ_REQUIRE(w->Hp == 64 || w->Hp == 128 || w->Hp == 256 || w->Hp == 512, "vocoder: dim_voc_latent / 2 = %d: the prenet scan is built "
+               "for 64, 128 (config.py:68), 256 and 512", w->Hp);
     VQ_REQUIRE(w->upsample_t > 0, "vocoder: upsample_t must be positive");
     vqcpc_vocoder *v = new vqcpc_vocoder();
     int rc = vocoder_create_impl(w, v);
@@ -1824,11 +1779,6 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
     if (!strcmp(name, "fuse_fc2")) {
         if ((value != 0) != (v->fuse_fc2 != 0)) clear_graphs(v);
         v->fuse_fc2 = value != 0;
-        return VQCPC_OK;
-    }
-    if (!strcmp(name, "fuse_fc1")) {
-        if ((value != 0) != (v->fuse_fc1 != 0)) clear_graphs(v);
-        v->fuse_fc1 = value != 0;
         return VQCPC_OK;
     }
     if (!strcmp(name, "persistent")) {
@@ -1948,20 +1898,60 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     return VQCPC_OK;
 }
 
+// Hidden sizes the per-sample kernels are instantiated for (size_h_rnn = 64 SW): 512, 896 (the reference's, config.py:76), 1024.
+// (Round 2 compiled nine values x every variant = ~190 kernels; a size outside the list is an explicit error at create.)
+#define AR_SW_CASES(X) X(8) X(14) X(16)
+
+static size_t big_lds_bytes(int Hr) { return (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float); }
+static bool use_big(const vqcpc_vocoder *v, int nbt) {
+    return v->big_min_tiles > 0 && nbt >= v->big_min_tiles && v->d.Hr % 16 == 0 && big_lds_bytes(v->d.Hr) <= 160 * 1024;
+}
+// One GRU-step launch for local step `tl`; nf = fc2 blocks of the previous step in front (fused launch, 0 = none).
+static int launch_gru_step(vqcpc_vocoder *v, const ArModel &m, const ArCall *call, int tl, int nbt, int nf, hipStream_t s) {
+    const int Hr = v->d.Hr, rgs = Hr / 4, npass = (nbt + 1) / 2;
+    const bool big = use_big(v, nbt);
+    const size_t lds = big_lds_bytes(Hr);
+    switch (Hr / 64) {
+#define CASE(k) case k: \
+        if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (Hr / 16) * npass), dim3(1024), lds, s, m, call, tl, nbt, nf); \
+        else if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, call, tl, nbt, nf); \
+        else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, call, tl, nbt, nf); \
+        else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, call, tl, nbt, nf); \
+        else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(rgs), dim3(320), 0, s, m, call, tl, nbt, 0); \
+        else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(Hr / 16, npass), dim3(1024), lds, s, m, call, tl, nbt, 0); \
+        else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(rgs, npass), dim3(384), 0, s, m, call, tl, nbt, 0); \
+        else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(rgs, npass), dim3(384), 0, s, m, call, tl, nbt, 0); \
+        break;
+        AR_SW_CASES(CASE)
+#undef CASE
+        default: vq_set_error("AR step: size_h_rnn %d unsupported", Hr); return VQCPC_ERR_INVALID;
+    }
+    return VQCPC_OK;
+}
+static int launch_fc1_step(vqcpc_vocoder *v, const ArModel &m, const ArCall *call, int tl, int nbt, hipStream_t s) {
+    const dim3 blk(256);
+    switch (v->d.Hr / 64) {
+#define CASE(k) case k: \
+        if (nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, nbt), blk, 0, s, m, call, tl, nbt); \
+        else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, call, tl, nbt); \
+        break;
+        AR_SW_CASES(CASE)
+#undef CASE
+        default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
+    }
+    return VQCPC_OK;
+}
+
 // tf: teacher-forced scan -- x_{t-1} comes from the inputs, so only the GRU step runs per sample (fc1 / fc2 follow
 // as batched GEMMs over the whole chunk, run_ar)
 static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int nbt, int n, bool tf, hipStream_t s) {
-    const int SW = v->d.Hr / 64;
     const dim3 blk(256);
-    // large-batch GRU kernel: >= big_min_tiles tiles in flight, Hr a multiple of 16, LDS fits
-    const size_t big_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
-    const bool big = v->big_min_tiles > 0 && nbt >= v->big_min_tiles && v->d.Hr % 16 == 0 && big_lds <= 160 * 1024;
+    const bool big = use_big(v, nbt);
     if (big && !v->big_attr_set) {
-        switch (SW) {
-#define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
-                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); \
-                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds)); break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
+        switch (v->d.Hr / 64) {
+#define CASE(k) case k: HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds_bytes(v->d.Hr))); \
+                        HIP_TRY(hipFuncSetAttribute((const void *)ar_gru_big_kernel<k, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds_bytes(v->d.Hr))); break;
+            AR_SW_CASES(CASE)
 #undef CASE
             default: break;
         }
@@ -1969,49 +1959,16 @@ static int launch_ar_steps(vqcpc_vocoder *v, const ArModel &m, ArCall *call, int
     }
     // Fused schedule (m.fused): step i = { fc2 of step i-1  ||  GRU of step i } in ONE launch, then fc1 of step i; the
     // fc2 of the replay's last step runs as a trailing launch (before the slot records change), so the first launch of a
-    // replay carries no fc2 blocks.
-    // Level 2 (m.fused == 2): fc1 of step i-1 rides along too -- ONE launch per sample; the trailing launch is fc1 + fc2.
-    const int rgs = v->d.Hr / 4, npass = (nbt + 1) / 2;
+    // replay carries no fc2 blocks.  (fc1 in the same launch as well -- one launch per sample -- was built and measured in
+    // round 2 and loses at every batch size: profiles/r02_gru_variants_one_launch.csv; removed.)
     const int f2_full = big ? (v->d.n_cls / 16) * nbt / 4 : (v->d.n_cls / 16) * nbt;
-    const int f1_full = big ? (v->d.Hf / 16) * nbt / 4 : (v->d.Hf / 8) * nbt;       // 16-row groups in teams of 4 / 8-row groups
     for (int i = 0; i < n; ++i) {
-        const int nf = (m.fused && i > 0) ? f2_full : 0;
-        const int n1 = (m.fused == 2 && i > 0) ? f1_full : 0;
-        switch (SW) {
-#define CASE(k) case k: \
-            if (m.fused == 2 && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 2>), dim3(n1 + nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, n1, nf); \
-            else if (m.fused == 2 && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 2>), dim3(n1 + nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, n1, nf); \
-            else if (m.fused == 2) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 2>), dim3(n1 + nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, n1, nf); \
-            else if (m.fused && big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * npass), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, nf); \
-            else if (m.fused && nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + rgs), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
-            else if (m.fused && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
-            else if (m.fused) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + rgs * npass), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, nf); \
-            else if (nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
-            else if (big) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (nbt + 1) / 2), dim3(1024), big_lds, s, m, (const ArCall *)call, i, nbt, 0, 0); \
-            else if (m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
-            else hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, i, nbt, 0, 0); \
-            if (tf || m.fused == 2) break; \
-            if (nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
-            else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, nbt), blk, 0, s, m, (const ArCall *)call, i, nbt); \
-            break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
-#undef CASE
-            default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
-        }
-        if (!tf && !m.fused) hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
+        TRY(launch_gru_step(v, m, call, i, nbt, (m.fused && i > 0) ? f2_full : 0, s));
+        if (tf) continue;
+        TRY(launch_fc1_step(v, m, call, i, nbt, s));
+        if (!m.fused) hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, i);
     }
-    if (!tf && m.fused == 1) hipLaunchKernelGGL(ar_fc2_kernel<1>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, n - 1);
-    if (!tf && m.fused == 2) {
-        switch (SW) {
-#define CASE(k) case k: \
-            if (nbt <= 4) hipLaunchKernelGGL((ar_fc12_kernel<k, 8>), dim3((v->d.Hf / 8 + v->d.n_cls / 16) * nbt), blk, 0, s, m, (const ArCall *)call, n - 1, nbt); \
-            else hipLaunchKernelGGL((ar_fc12_kernel<k, 16>), dim3((v->d.Hf / 16 + v->d.n_cls / 16) * nbt), blk, 0, s, m, (const ArCall *)call, n - 1, nbt); \
-            break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
-#undef CASE
-            default: break;
-        }
-    }
+    if (!tf && m.fused) hipLaunchKernelGGL(ar_fc2_kernel<1>, dim3(v->d.n_cls / 16, nbt), blk, 0, s, m, (const ArCall *)call, n - 1);
     if (!tf) hipLaunchKernelGGL(ar_finalize_kernel, dim3((nbt * 16 + 63) / 64), dim3(64), 0, s, m, (const ArCall *)call);
     hipLaunchKernelGGL(ar_advance_kernel, dim3(1), dim3(1), 0, s, call, n);
     hipLaunchKernelGGL(ar_next_row_kernel, dim3(nbt * 16), dim3(256), 0, s, m, (const ArCall *)call);
@@ -2215,18 +2172,16 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         const size_t hsz = (size_t)nb * Hr * 16 * sizeof(float);
         TRY(G.har.reserve(2 * hsz));
         TRY(G.a1.reserve((size_t)nb * d.Hf * 16 * sizeof(float)));
-        TRY(G.cand_s.reserve((size_t)Spg * 16 * sizeof(float)));
-        TRY(G.cand_k.reserve((size_t)Spg * 16 * sizeof(int)));
+        const size_t nrg = (size_t)d.n_cls / 16;
+        TRY(G.cand_s.reserve((size_t)Spg * nrg * sizeof(float)));
+        TRY(G.cand_k.reserve((size_t)Spg * nrg * sizeof(int)));
         TRY(G.gcur.reserve((size_t)Spg * Hr * sizeof(float4)));
         HIP_TRY(hipMemsetAsync(G.har.p, 0, 2 * hsz, s));
-        HIP_TRY(hipMemsetAsync(G.cand_s.p, 0, (size_t)Spg * 16 * sizeof(float), s));
-        HIP_TRY(hipMemsetAsync(G.cand_k.p, 0, (size_t)Spg * 16 * sizeof(int), s));
-        const size_t cg_bytes = (size_t)nb * 16 * 16 * sizeof(u64);          // granules, then one 64-byte block for the abort word
+        HIP_TRY(hipMemsetAsync(G.cand_s.p, 0, (size_t)Spg * nrg * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(G.cand_k.p, 0, (size_t)Spg * nrg * sizeof(int), s));
+        const size_t cg_bytes = (size_t)nb * nrg * 16 * sizeof(u64);          // granules, then one 64-byte block for the abort word
         TRY(G.candg.reserve(cg_bytes + 64));
         HIP_TRY(hipMemsetAsync(G.candg.p, 0, cg_bytes + 64, s));
-        const size_t a1g_bytes = (size_t)nb * d.Hf * 16 * sizeof(u64);       // fc1 outputs as granules (fused level 2)
-        TRY(G.a1g.reserve(a1g_bytes));
-        HIP_TRY(hipMemsetAsync(G.a1g.p, 0, a1g_bytes, s));
         ArCall &c = calls[g];
         c = ArCall{};
         c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
@@ -2252,7 +2207,6 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         }
         m.lead6 = n_grp == 2 && nb <= 2;
         m.candg = G.candg.as<u64>();
-        m.a1g = G.a1g.as<u64>();
         m.abort_dev = (unsigned *)((char *)G.candg.p + cg_bytes);
         m.abort_host = abort_dev_ptr;
         m.timeout_ticks = (unsigned)v->handoff_timeout_ms * 100000u;
@@ -2261,7 +2215,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
             const size_t big_lds = (size_t)2 * Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
             const bool big = v->big_min_tiles > 0 && nb >= v->big_min_tiles && Hr % 16 == 0 && big_lds <= 160 * 1024;
             (void)big;
-            m.fused = (v->fuse_fc2 && !tf && gmax[g] < (1 << 24)) ? (v->fuse_fc1 ? 2 : 1) : 0;
+            m.fused = (v->fuse_fc2 && !tf && gmax[g] < (1 << CAND_TAG_BITS)) ? 1 : 0;
         }
         m.Hr = Hr; m.Hf = d.Hf; m.n_cls = d.n_cls; m.upsample = d.upsample_t;
     }
@@ -2274,7 +2228,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         for (int g = 0; g < n_grp; ++g) {
             auto &G = v->grp[g];
             // a graph bakes its ArModel (buffer pointers): drop cached graphs if a workspace moved
-            const void *now[8] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p, G.candg.p, G.a1g.p};
+            const void *now[8] = {G.har.p, G.a1.p, G.cand_s.p, G.cand_k.p, G.cur.p, G.gcur.p, G.candg.p, nullptr};
             if (memcmp(G.baked, now, sizeof now) != 0) {
                 for (auto &kv : G.graphs) (void)hipGraphExecDestroy(kv.second);
                 G.graphs.clear();
@@ -2364,12 +2318,9 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
     HIP_TRY(hipMemcpyAsync(call, &c, sizeof c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     const ArModel m = v->last_model;
-    const int SW = v->d.Hr / 64;
     const dim3 blk(256);
-    const size_t tbig_lds = (size_t)2 * v->d.Hr * 16 * sizeof(float) + (size_t)2 * 3 * 4 * 16 * 17 * sizeof(float);
-    const bool tbig = v->big_attr_set && v->big_min_tiles > 0 && c.nbt >= v->big_min_tiles && v->d.Hr % 16 == 0;
+    const bool tbig = use_big(v, c.nbt);
     const int nf = tbig ? (v->d.n_cls / 16) * c.nbt / 4 : (v->d.n_cls / 16) * c.nbt;   // fused launch: fc2 blocks of step t-1 in front of the GRU blocks of step t
-    const int n1 = m.fused == 2 ? (tbig ? (v->d.Hf / 16) * c.nbt / 4 : (v->d.Hf / 8) * c.nbt) : 0;   // ... and fc1 blocks in front of those
     int fresh = 0;                       // fused launches so far
     for (int which = 0; which < 3; ++which) {
         for (int pass = 0; pass < 2; ++pass) {          // pass 0 = warm-up
@@ -2377,28 +2328,10 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
             const int n = pass == 0 ? 20 : reps;
             for (int i = 0; i < n; ++i) {
                 if (which == 2) { hipLaunchKernelGGL(ar_fc2_kernel<0>, dim3(v->d.n_cls / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0); continue; }
+                if (which == 1) { TRY(launch_fc1_step(v, m, call, 0, c.nbt, s)); continue; }
                 const int period = c.max_t > 5 ? (c.max_t - 3) / 2 : 1;              // keep t = t_base + tl inside the call (reps beyond
-                const int tl = 1 + 2 * ((which == 0 && m.fused) ? fresh++ % period : 0);   // that reuse steps, i.e. find their tags in place)
-                switch (SW) {
-#define CASE(k) case k: \
-                    if (which == 0 && m.fused == 2 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 2>), dim3(n1 + nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, tl, c.nbt, n1, nf); \
-                    else if (which == 0 && m.fused == 2 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 2>), dim3(n1 + nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, tl, c.nbt, n1, nf); \
-                    else if (which == 0 && m.fused == 2) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 2>), dim3(n1 + nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, n1, nf); \
-                    else if (which == 0 && m.fused && !tbig && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 1>), dim3(nf + v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
-                    else if (which == 0 && m.fused && !tbig && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
-                    else if (which == 0 && m.fused && !tbig) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 1>), dim3(nf + (v->d.Hr / 4) * ((c.nbt + 1) / 2)), dim3(384), 0, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
-                    else if (which == 0 && c.nbt == 1) hipLaunchKernelGGL((ar_gru_kernel<k, 1, 3, 0>), dim3(v->d.Hr / 4), dim3(320), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
-                    else if (which == 0 && tbig && m.fused) hipLaunchKernelGGL((ar_gru_big_kernel<k, 1>), dim3(nf + (v->d.Hr / 16) * ((c.nbt + 1) / 2)), dim3(1024), tbig_lds, s, m, (const ArCall *)call, tl, c.nbt, 0, nf); \
-                    else if (which == 0 && tbig) hipLaunchKernelGGL((ar_gru_big_kernel<k, 0>), dim3(v->d.Hr / 16, (c.nbt + 1) / 2), dim3(1024), tbig_lds, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
-                    else if (which == 0 && m.lead6) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 6, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
-                    else if (which == 0) hipLaunchKernelGGL((ar_gru_kernel<k, 2, 3, 0>), dim3(v->d.Hr / 4, (c.nbt + 1) / 2), dim3(384), 0, s, m, (const ArCall *)call, 0, c.nbt, 0, 0); \
-                    else if (c.nbt <= 4) hipLaunchKernelGGL((ar_fc1_kernel<k, 8>), dim3(v->d.Hf / 8, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
-                    else hipLaunchKernelGGL((ar_fc1_kernel<k, 16>), dim3(v->d.Hf / 16, c.nbt), blk, 0, s, m, (const ArCall *)call, 0, c.nbt); \
-                    break;
-                    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(14) CASE(16)
-#undef CASE
-                    default: vq_set_error("AR step: size_h_rnn %d unsupported", v->d.Hr); return VQCPC_ERR_INVALID;
-                }
+                const int tl = m.fused ? 1 + 2 * (fresh++ % period) : 0;             // that reuse steps, i.e. find their tags in place)
+                TRY(launch_gru_step(v, m, call, tl, c.nbt, m.fused ? nf : 0, s));
             }
         }
         HIP_TRY(hipEventRecord(v->ev1, s));
@@ -2408,7 +2341,7 @@ extern "C" int vqcpc_vocoder_kernel_times(vqcpc_vocoder *v, int reps, float *out
         out_us[which] = ms * 1e3f / (float)reps;
     }
     out_us[3] = (float)(c.nbt * 16);       // decode slots one launch of the timed configuration covers
-    out_us[4] = m.fused == 2 ? (tbig ? 7.f : 6.f) : m.fused ? (tbig ? 5.f : 4.f) : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
+    out_us[4] = m.fused ? (tbig ? 5.f : 4.f) : (c.nbt == 1 ? 0.f : (tbig ? 2.f : 1.f));    // which GRU-step kernel that configuration runs
     return VQCPC_OK;
 }
 
