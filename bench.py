@@ -300,6 +300,51 @@ def run_manifest(enc, voc, dev, n_utt, max_batch):
                          "how": "6 782 976 FLOP per decoded sample x samples of the manifest / decode loop time (HIP events)"}}
 
 
+def run_convert_e2e(enc, voc, dev, n_utt, slots):
+    """`convert.py:52-83` end to end, wav files in -> wav files out, as `python -m vectorquantizedcpc_amd.cli convert` runs it:
+    `n_utt` synthetic 22.05 kHz int16 wavs on disk (log-normal 1-10 s, seeded) -> read -> resample to 16 kHz -> reference
+    loudness -> log-mel (all three batched per length bucket on the GPU) -> encode -> decode (continuous batching over `slots`
+    decode slots) -> loudness re-normalisation -> float32 wav files.  Wall seconds per stage (device synchronised at every
+    stage boundary) and their shares; writing the synthetic inputs is not timed."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from scipy.io import wavfile
+    from vectorquantizedcpc_amd import cli
+    frames, spk = synthetic_manifest(n_utt)
+    tmp = tempfile.mkdtemp(prefix="vqcpc_e2e_")
+    try:
+        in_dir, out_dir = os.path.join(tmp, "in"), os.path.join(tmp, "out")
+        os.makedirs(in_dir), os.makedirs(out_dir)
+        entries = []
+        for i, f in enumerate(frames):
+            n = int(f * 160 * 22050 / 16000)
+            u = synth.uniform01(f"e2e/{i % 16}", n + 64, synth.SEED)[:n]
+            env = 0.25 + 0.5 * np.abs(np.sin(np.arange(n) * (2 * np.pi / 22050.0) * (0.7 + 0.1 * (i % 5))))
+            wavfile.write(os.path.join(in_dir, f"u{i:04d}.wav"), 22050, ((u * 2.0 - 1.0) * env * 20000).astype(np.int16))
+            entries.append((os.path.join(in_dir, f"u{i:04d}"), spk[i], f"o{i:04d}"))
+        cli.convert_files(enc, voc, entries[:8], out_dir, synth.SEED, slots=slots)          # warm-up: handles, graphs, tables
+        torch.cuda.synchronize(dev)
+        tm = {}
+        t0 = time.perf_counter()
+        wavs = cli.convert_files(enc, voc, entries, out_dir, synth.SEED, slots=slots, timings=tm)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        samples = sum(int(w.numel()) for w in wavs)
+        n_out = len([f for f in os.listdir(out_dir) if f.endswith(".wav")])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    front = sum(tm.get(k, 0.0) for k in ("read_files", "upload", "resample", "loudness_in", "mel"))
+    back = sum(tm.get(k, 0.0) for k in ("loudness_out", "download", "write_files"))
+    return {"workload": f"convert.py:52-83 end to end: {n_utt} wav files at 22.05 kHz (log-normal 1-10 s) -> resample -> loudness -> "
+                        f"log-mel -> encode -> decode ({slots} slots) -> loudness -> {n_out} wav files at 16 kHz",
+            "utterances": n_utt, "audio_seconds": samples / 16000.0, "wall_s": wall, "samples_per_s": samples / wall,
+            "realtime_factor_16k": samples / 16000.0 / wall,
+            "stage_s": {k: round(v, 4) for k, v in tm.items()},
+            "stage_share": {k: round(v / wall, 4) for k, v in tm.items()},
+            "front_end_and_io_share": (front + back) / wall, "model_share": (tm.get("encode", 0.0) + tm.get("decode", 0.0)) / wall}
+
+
 def gru_roofline(voc, n_utt, step_us, n_steps=0):
     """`roofline` object for the GRU-step kernel of the LAST generate() call: HIP events around 2000
     back-to-back launches on the launch stream (vqcpc_vocoder_kernel_times)."""
@@ -564,6 +609,9 @@ def main():
     if solo and args.manifest > 0:
         log(f"manifest workload: {args.manifest} utterances")
         result["manifest"] = run_manifest(enc, voc, dev, args.manifest, args.manifest_batch)
+    if solo and args.manifest > 0 and not args.no_extras:
+        log(f"convert end to end: {args.manifest} wav files")
+        result["convert_e2e"] = run_convert_e2e(enc, voc, dev, args.manifest, args.manifest_batch)
     if solo and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Bp)
     if rank == 0:

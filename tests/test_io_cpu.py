@@ -72,3 +72,27 @@ def test_vocoder_checkpoint_keys_are_matched_by_suffix_and_shape(tmp_path):
     with pytest.raises(KeyError) as ei:
         io.remap_state_dict(bad, vsd)
     assert "rnnms.ar.fc1.bias" in str(ei.value) and "rnnms.something.else" in str(ei.value)
+
+
+def test_wav_decode_scales_integers_before_the_mono_mean(tmp_path):
+    """librosa.load(mono=True) / soundfile semantics (convert.py:54-56): int16 / 2^15, int32 / 2^31, uint8 (a - 128) / 128, THEN
+    the channel mean.  (Averaging first turned a stereo int16 file into unscaled floats around +-32768: ADVICE r2.)"""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(3)
+    st16 = rng.integers(-20000, 20000, size=(4000, 2), dtype=np.int16)
+    wavfile.write(str(tmp_path / "st16.wav"), 16000, st16)
+    rate, a = io.read_wav_file(tmp_path / "st16")
+    assert rate == 16000 and a.dtype == np.float32 and a.shape == (4000,)
+    assert np.allclose(a, st16.astype(np.float64).mean(axis=1) / 32768.0, atol=1e-7) and np.abs(a).max() < 1.0
+    assert torch.equal(io.load_wav(tmp_path / "st16"), torch.from_numpy(a))
+    m32 = (rng.integers(-2 ** 30, 2 ** 30, size=3000)).astype(np.int32)
+    wavfile.write(str(tmp_path / "m32.wav"), 16000, m32)
+    assert np.allclose(io.read_wav_file(tmp_path / "m32")[1], m32 / 2.0 ** 31, atol=1e-7)
+    u8 = rng.integers(0, 256, size=(2000, 2), dtype=np.uint8)
+    wavfile.write(str(tmp_path / "u8.wav"), 16000, u8)
+    got = io.read_wav_file(tmp_path / "u8")[1]
+    assert np.allclose(got, ((u8.astype(np.float64) - 128.0) / 128.0).mean(axis=1), atol=1e-7) and got.min() >= -1.0 and got.max() < 1.0
+    f32 = rng.uniform(-0.5, 0.5, size=(1000, 2)).astype(np.float32)
+    wavfile.write(str(tmp_path / "f32.wav"), 22050, f32)
+    rate, a = io.read_wav_file(tmp_path / "f32")
+    assert rate == 22050 and np.allclose(a, f32.mean(axis=1), atol=1e-7)

@@ -67,27 +67,59 @@ def encode_dataset(args) -> int:
     return 0
 
 
+def convert_files(enc, voc, entries, out_dir, seed, max_batch: int = 64, slots: int = 0, timings=None):
+    """``convert.py:52-83`` over ``entries`` = [(input path without suffix, speaker id, output name)]: ``.mel.npy`` inputs
+    are used as they are; ``.wav`` inputs go through the batched HIP front end (resample at load, reference loudness, log-mel:
+    ``driver.front_end_utterances``) and their outputs are re-normalised to the input's loudness (``convert.py:79-80``).
+    ``timings``: a dict that receives wall seconds per stage (the device is synchronised at every stage boundary then)."""
+    import time
+    dev = next(enc.parameters()).device
+    t_last = [time.perf_counter()]
+
+    def clock(name):
+        if timings is None:
+            return
+        torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + now - t_last[0]
+        t_last[0] = now
+
+    mels = [None] * len(entries)
+    wav_ids, waves, rates = [], [], []
+    for i, (p, _, _) in enumerate(entries):
+        if Path(p).with_suffix(".mel.npy").exists():
+            mels[i] = io.load_mel(p).to(dev)
+        else:
+            rate, a = io.read_wav_file(p)
+            wav_ids.append(i); waves.append(a); rates.append(rate)
+    clock("read_files")
+    ref = {}
+    if wav_ids:
+        fm, fl = driver.front_end_utterances(waves, rates, dev, max_batch=max_batch, clock=clock)
+        for i, m, l in zip(wav_ids, fm, fl):
+            mels[i] = m
+            ref[i] = l
+    wavs = driver.convert_utterances(enc, voc, mels, [s for _, s, _ in entries], seed=seed, max_batch=max_batch, slots=slots,
+                                     clock=clock)
+    if ref:                                                    # convert.py:79-80, one batched call each way
+        ids = sorted(ref)
+        for i, w in zip(ids, loudness.match_loudness([wavs[i] for i in ids], [ref[i] for i in ids])):
+            wavs[i] = w
+    clock("loudness_out")
+    host = [w.cpu() for w in wavs]
+    clock("download")
+    for (_, _, name), w in zip(entries, host):
+        io.save_wav(Path(out_dir) / name, w, 16000)
+    clock("write_files")
+    return wavs
+
+
 def convert_dataset(args) -> int:
     items, _ = io.read_synthesis_list(args.synthesis_list, Path(args.dataset) / "speakers.json")
     in_dir, out_dir = Path(args.in_dir), Path(args.out_dir)
     out_dir.mkdir(exist_ok=True, parents=True)
     enc, voc = _models(args, need_vocoder=True)
-    mels, ref = [], {}
-    meter = loudness.Meter(16000)                              # convert.py:50
-    for i, (p, _, _) in enumerate(items):
-        if (in_dir / p).with_suffix(".mel.npy").exists():
-            mels.append(io.load_mel(in_dir / p))
-        else:                                                  # convert.py:54-70: wav -> log-mel, on the GPU
-            wav = io.load_wav(in_dir / p).to(args.device)
-            ref[i] = meter.integrated_loudness(wav)            # convert.py:57 (before the peak normalisation)
-            mels.append(preprocess.wave_to_mel(wav))
-    wavs = driver.convert_utterances(enc, voc, mels, [s for _, s, _ in items], seed=args.seed, max_batch=args.max_batch)
-    if ref:                                                    # convert.py:79-80, one batched call each way
-        ids = sorted(ref)
-        for i, w in zip(ids, loudness.match_loudness([wavs[i] for i in ids], [ref[i] for i in ids])):
-            wavs[i] = w
-    for (_, _, name), w in zip(items, wavs):
-        io.save_wav(out_dir / name, w, 16000)
+    convert_files(enc, voc, [(in_dir / p, s, name) for p, s, name in items], out_dir, args.seed, max_batch=args.max_batch)
     print(f"converted {len(items)} utterances -> {out_dir}")
     return 0
 

@@ -104,7 +104,7 @@ def encode_utterances(encoder: Encoder, mels: Sequence[torch.Tensor], want_conte
 @torch.no_grad()
 def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.Tensor], speakers: Sequence[int],
                        seed: int, utt_ids: Optional[Sequence[int]] = None, max_batch: int = 64,
-                       max_pad_frac: float = 0.25, slots: int = 0) -> List[torch.Tensor]:
+                       max_pad_frac: float = 0.25, slots: int = 0, clock=None) -> List[torch.Tensor]:
     """``convert.py:72-77`` over a list of utterances -> list of 1-D waveforms (160 * 2 * T_i' samples).
 
     ``slots`` > 0: continuous batching -- ONE decode call over all utterances with that many decode
@@ -123,6 +123,7 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
     for ids in make_buckets(lengths, modes, max_batch, max_pad_frac):
         batch = _pad_stack(mels, ids, dev)
         idx = encoder._encode_native(batch, want_c=False, conv_mode=modes[ids[0]])[2]
+        if clock: clock("encode")
         if slots > 0:
             for k, i in enumerate(ids):
                 codes[i] = idx[k, : n_codes_all[i]]
@@ -130,6 +131,7 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
         n_codes = [n_codes_all[i] for i in ids]
         spk = torch.tensor([int(speakers[i]) for i in ids], device=dev)
         wav = generate_checked(vocoder, idx, spk, n_codes=n_codes, seed=seed, utt_ids=[utt_ids[i] for i in ids])
+        if clock: clock("decode")
         for k, i in enumerate(ids):
             out[i] = wav[k, : 2 * up * n_codes[k]]
     if slots > 0:
@@ -142,6 +144,43 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
             wav = generate_checked(vocoder, idx, spk, n_codes=n_codes_all, seed=seed, utt_ids=utt_ids)
         finally:
             vocoder.set_option("slots", 0)
+        if clock: clock("decode")
         for i in range(len(mels)):
             out[i] = wav[i, : 2 * up * n_codes_all[i]]
     return out
+
+
+@torch.no_grad()
+def front_end_utterances(waves, rates, device, sr: int = 16000, max_batch: int = 64, max_pad_frac: float = 0.25, conf=None,
+                         clock=None):
+    """``convert.py:54-70`` for a list of mono waveforms (numpy / CPU tensors at their files' own rates): resample to ``sr``
+    (``librosa.load(sr=...)``), reference loudness (``convert.py:57``, before the peak normalisation), log-mel -- each ONE
+    batched call per length bucket instead of three synchronising calls per utterance (the C ABI takes (B, Lmax) + lengths).
+    Returns (list of (80, T_i) device mels, list of float reference LUFS).  ``clock(name)``: optional stage timer."""
+    from . import loudness, preprocess
+    n = len(waves)
+    mels, ref = [None] * n, [None] * n
+    meter = loudness.Meter(sr)
+    lens_in = [int(len(w)) for w in waves]
+    hop = (conf or preprocess.ConfPreprocessing()).hop_length
+    for ids in make_buckets(lens_in, [int(r) for r in rates], max_batch, max_pad_frac):
+        rate = int(rates[ids[0]])
+        L = max(lens_in[i] for i in ids)
+        batch = torch.zeros(len(ids), L, device=device)               # each utterance straight into its padded row (one copy)
+        for k, i in enumerate(ids):
+            batch[k, : lens_in[i]].copy_(torch.as_tensor(waves[i], dtype=torch.float32), non_blocking=True)
+        lens = [lens_in[i] for i in ids]
+        if clock: clock("upload")
+        if rate != sr:
+            batch = preprocess.resample(batch, rate, sr, lengths=lens)
+            lens = [-(-l * sr // rate) for l in lens]                       # ceil(l * sr / rate), as librosa.resample(fix=True)
+            if clock: clock("resample")
+        lufs = meter.integrated_loudness(batch, lengths=lens)
+        if clock: clock("loudness_in")
+        mel = preprocess.wave_to_mel(batch, conf, lengths=lens)
+        lufs = lufs.tolist()
+        for k, i in enumerate(ids):
+            mels[i] = mel[k, :, : 1 + lens[k] // hop]
+            ref[i] = lufs[k]
+        if clock: clock("mel")
+    return mels, ref

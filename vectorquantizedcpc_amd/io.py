@@ -28,17 +28,29 @@ def load_mel(path) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 
+def read_wav_file(path) -> Tuple[int, np.ndarray]:
+    """(rate, mono float32 samples in [-1, 1]) of a WAV file as soundfile / librosa decode it: integer PCM is scaled by its
+    full range FIRST (int16 / 2^15, int32 / 2^31, uint8 (a - 128) / 128), then the channels are averaged
+    (``librosa.load(mono=True)``) -- averaging first would turn the integers into floats that are never scaled."""
+    from scipy.io import wavfile
+    rate, a = wavfile.read(str(Path(path).with_suffix(".wav")))
+    if a.dtype.kind == "i":
+        a = a.astype(np.float32) / float(np.iinfo(a.dtype).max + 1)
+    elif a.dtype.kind == "u":
+        a = (a.astype(np.float32) - 128.0) / 128.0
+    else:
+        a = a.astype(np.float32)
+    if a.ndim > 1:
+        a = a.mean(axis=1, dtype=np.float32)
+    return int(rate), np.ascontiguousarray(a, dtype=np.float32)
+
+
 def load_wav(path, sr: int = 16000) -> torch.Tensor:
     """Mono waveform at ``sr`` as float32 in [-1, 1]: ``librosa.load(path, sr=sr)`` (``convert.py:54-56``).  A file stored
     at another rate is resampled like librosa does (``preprocess.resample``: kaiser_best sinc interpolation, on the HIP
     device -- so that case needs a GPU; the result comes back as a CPU tensor like the other case)."""
-    from scipy.io import wavfile
-    rate, a = wavfile.read(str(Path(path).with_suffix(".wav")))
-    if a.ndim > 1:
-        a = a.mean(axis=1)                    # librosa.load(mono=True)
-    if a.dtype.kind == "i":
-        a = a.astype(np.float32) / float(np.iinfo(a.dtype).max + 1)
-    w = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    rate, a = read_wav_file(path)
+    w = torch.from_numpy(a)
     if rate != sr:
         from .preprocess import resample
         w = resample(w.cuda(), rate, sr).cpu()
