@@ -21,11 +21,13 @@
 //
 // Roles of the 12 waves of a workgroup:
 //   waves 0..9   W_hh h_t chains of rows 0..79 for every slot of the XCD (8 rows per wave, weights pinned in VGPRs) -> gsum
-//   wave 11 / 10 everything that is serial in a sample step, for the even / odd slots: x_{t-1} from the slot's 32
-//                candidates; cell update of the 28 owned units; publish h_t; fc1 (weights streamed from LDS) -> publish
-//                a_t; sweep of a_t; fc2 + Gumbel-max candidate -> publish; and, in the shadow of the a_t exchange, W_hh
-//                rows 80..83 for the OTHER wave's slots (one chain pass: a half wave per slot)
-//   wave 0       also draws the next step's Gumbel noise (Philox + two logs per class) in its idle time
+//   wave b < bx  also: sweep of a_t of slot b, fc2 + Gumbel-max candidate of the 8 owned classes -> publish (between its W_hh
+//                chains: one slot per wave, in parallel)
+//   wave 11 / 10 what else is serial in a sample step, for the even / odd slots: cell update of the 28 owned units; publish
+//                h_t; the slot's state for the next step in the shadow of the h_t exchange; fc1 (weights streamed from LDS)
+//                -> publish a_t; W_hh rows 80..83 for the OTHER wave's slots (one chain pass: a half wave per slot); the
+//                next step's Gumbel noise (Philox + two logs per class); x_t from the slot's 32 candidates, picked up
+//                before barrier B
 //   all waves    sweep h_t into LDS
 // Two workgroup barriers per sample.  Every wait is wall-clock bounded; a timeout sets status bit 0, every workgroup
 // leaves, and the call's outputs are incomplete (vqcpc_vocoder_check reports it).
@@ -415,16 +417,14 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             const unsigned gate = row_local / UPB, ul = row_local - gate * UPB;
             ps_load_weights<HR / 64>(p.w_hh + (size_t)(gate * HR + UPB * rank + ul) * HR, kw, c0, w);
         }
-        // wave 0 also draws the Gumbel noise of the NEXT step in its idle time (class lane & 7 of slot lane >> 3): it does
-        // not depend on the data, only on (sample index, utterance) of the slot, which the service waves post in sinfo
-        const unsigned ncls = FPB * rank + (lane & 7u);
-        const int nb = (int)(lane >> 3);
-        ps_barrier();                                                      // state of step 0 posted
-        if (wave == 0 && nb < bx) {
-            const unsigned wd = philox_word((unsigned)sinfo[nb * 4 + 0], (unsigned)sinfo[nb * 4 + 1], ncls >> 2, (unsigned)p.seed,
-                                            (unsigned)(p.seed >> 32), (int)(ncls & 3u));
-            noise[nb * 8 + (lane & 7u)] = gumbel_from_word(wd);
-        }
+        // wave b < bx also runs fc2 + the draw of slot b (one slot per wave, in parallel), between its W_hh chains: a_t of the
+        // slot arrives while the first chains run
+        const bool fc2_wave = wave < bx;
+        const int fc2_after = bx < 3 ? bx : 3;                             // chains done before it looks for a_t
+        const float b2 = p.b_fc2[FPB * rank + r8];
+        const float4 *wp2 = (const float4 *)(fc2w + (r8 * 8 + cid) * NT_A);
+        const float *opnd2 = ac + wave * HF + cid * NT_A + 8 * j;
+        ps_barrier();                                                      // state and noise of step 0 posted
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
             XD_SWEEP_H();
@@ -434,11 +434,54 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 const float acc = chain_regs<NT_H>(w, opnd + b * HR);
                 const float v = chain_combine(acc);
                 if (sum_lane) gsum[b * 96 + row_local] = v;
-            }
-            if (wave == 0 && nb < bx) {                                  // noise of step t + 1 into the other buffer
-                const unsigned wd = philox_word((unsigned)sinfo[nb * 4 + 0], (unsigned)sinfo[nb * 4 + 1], ncls >> 2, (unsigned)p.seed,
-                                                (unsigned)(p.seed >> 32), (int)(ncls & 3u));
-                noise[((t + 1) & 1) * (BXT * 8) + nb * 8 + (lane & 7u)] = gumbel_from_word(wd);
+                if (fc2_wave && b + 1 == fc2_after) {
+                    // ---- a_t of slot `wave` (256 granules, 4 per lane) -> fc2 -> Gumbel-max candidate of the 8 owned classes
+                    const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)wave) << 3) + (lane & 7u)) * 8u;
+                    const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);
+                    float4 wa = wp2[0], wb = wp2[1];                     // first weights and the noise: on their way during the sweep
+                    const float nz = noise[(t & 1) * (BXT * 8) + wave * 8 + r8];
+                    u64 va[4];
+                    wt.start();
+                    for (unsigned spins = 0;; ++spins) {
+                        gran_load4b<512 * BXT>(va, ga, ga + 128 * BXT, aoff);
+                        bool ok = true;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ok &= (unsigned)(va[i] >> 32) == tag;
+                        if (__all(ok)) break;
+                        if (wt.expired(spins, lane)) { *s_abort = 1; break; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ac[wave * HF + 64 * i + adst] = __uint_as_float((unsigned)va[i]);
+                    XD_STAMP(0, 8);
+                    const float4 a0 = ((const float4 *)opnd2)[0], a1 = ((const float4 *)opnd2)[1];
+                    const float hv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    float acc2 = 0.f;
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) {                            // 32 terms: 8 per quad lane, weights two 16-byte words at a time
+                        float4 na = wa, nb2 = wb;
+                        if (J < 3) { na = wp2[2 * J + 2]; nb2 = wp2[2 * J + 3]; }
+                        const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                        if (J == 0) fmac8<0>(acc2, hv, w8);
+                        if (J == 1) fmac8<1>(acc2, hv, w8);
+                        if (J == 2) fmac8<2>(acc2, hv, w8);
+                        if (J == 3) fmac8<3>(acc2, hv, w8);
+                        wa = na; wb = nb2;
+                    }
+                    float v2 = chain_combine(acc2);
+                    v2 += b2;
+                    const float sc = v2 + nz;                                // classes 0..3 of the 8 in lanes 0..3, 4..7 in lanes 32..35
+                    float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 0));
+                    int kb = 0;
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) {
+                        const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), k < 4 ? k : 28 + k));
+                        if (sk > best) { best = sk; kb = k; }
+                    }
+                    const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
+                    if (lane == 0 && !drop)
+                        xd_put(gc, ((unsigned)rank * 16 + wave) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                    XD_STAMP(0, 9);
+                }
             }
             XD_STAMP(0, 6);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
@@ -446,23 +489,19 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         }
     } else {
         // =====================================================================================  service waves
-        // Wave 11 (sv 0) owns the even slots of the XCD, wave 10 (sv 1) the odd ones, for everything that is serial in a
-        // sample step: x_{t-1} from the slot's 32 candidates, the cell update of the 28 owned units, h_t published,
-        // fc1 -> a_t published, a_t gathered, fc2 + Gumbel-max candidate published; and, in the shadow of the a_t exchange,
-        // W_hh rows 80..83 for the OTHER wave's slots.  Half wave hw of the cell update takes slot sv + 2 hw.
+        // Wave 11 (sv 0) owns the even slots of the XCD, wave 10 (sv 1) the odd ones, for what is serial in a sample step
+        // and not a chain wave's: x_{t-1} from the slot's 32 candidates, the cell update of the 28 owned units, h_t
+        // published, fc1 -> a_t published; and, behind those, W_hh rows 80..83 for the OTHER wave's slots and the next
+        // step's Gumbel noise.  Half wave hw of the cell update takes slot sv + 2 hw.
         const int sv = 11 - wave;
         const int hw = (int)(lane >> 5);
         const int cb = sv + 2 * hw;                                     // slot of this half wave in the cell update
         const unsigned cu = lane & 31u;                                 // unit
         const int n_own = bx > sv ? (bx - sv + 1) / 2 : 0;              // slots sv, sv + 2 < bx
         const bool cell_on = cb < bx;
-        const float b1 = p.b_fc1[FPB * rank + r8], b2 = p.b_fc2[FPB * rank + r8];
-        const float *opnd2 = ac + cid * NT_A + 8 * j;
-        const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)sv) << 3) + (lane & 7u)) * 8u;   // a_t granule of (rank lane >> 3 (+ 8 i), slot sv, row lane & 7), bytes
-        const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);   // chain_pos(4, lane + 64 i) - 64 i
+        const float b1 = p.b_fc1[FPB * rank + r8];
         const float4 *wp1 = (const float4 *)(fc1w + (r8 * 8 + cid) * NT_H);
         const float4 *wpx = (const float4 *)(whx + ((r8 & 3u) * 8 + cid) * NT_H);
-        const float4 *wp2 = (const float4 *)(fc2w + (r8 * 8 + cid) * NT_A);
         const float bq0 = c_bq[cu], bq1 = c_bq[32 + cu], bq2 = c_bq[64 + cu];
         const u64 *csrc = gc + ((lane & 31u) * 16 + (unsigned)(cb < BXT ? cb : 0));
         // W_hh rows 80..83 for the other wave's slots 1 - sv and 3 - sv: the lower half wave takes the first, the upper half the second
@@ -473,7 +512,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
 
         // ---- slot state, one step ahead: what the cell update of step `tn` will need that does not depend on the data
         bool st_active = false, st_first = false, st_emit = false;
-        int st_erow = 0, st_eidx = 0;
+        int st_erow = 0, st_eidx = 0, st_lt = 0;
+        unsigned st_utt = 0u;
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, hprev = 0.f;
         auto advance = [&](int tn) {
             st_active = false; st_first = false; st_emit = false;
@@ -495,6 +535,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             st_active = row >= 0 && lt >= 0 && lt < len;
             st_first = lt == 0;
+            st_lt = lt; st_utt = utt;
             if (st_active) {
                 if (fpos == p.upsample) { fpos = 0; fidx += 1; }
                 if (fpos == 0 && cu < UPB) {                         // next conditioning frame (once per hop)
@@ -505,54 +546,37 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 fpos += 1;
                 if (cu == 0) { seg_st[cb * 8 + 5] = fpos; seg_st[cb * 8 + 6] = fidx; }
             }
-            if (cu == 0) { sinfo[cb * 4 + 0] = lt; sinfo[cb * 4 + 1] = (int)utt; }
+        };
+        // the Gumbel noise of step `tn`'s draw (it does not depend on the data): class lane & 7 of slot sv + 2 ((lane >> 3) & 1)
+        auto draw_noise = [&](int tn) {
+            const int lt_b = __builtin_amdgcn_readlane(st_lt, 0), lt_b2 = __builtin_amdgcn_readlane(st_lt, 32);
+            const unsigned ut_b = __builtin_amdgcn_readlane(st_utt, 0), ut_b2 = __builtin_amdgcn_readlane(st_utt, 32);
+            if (lane < 16) {
+                const int which = (int)(lane >> 3), b = sv + 2 * which;
+                if (b < bx) {
+                    const unsigned cls = FPB * rank + (lane & 7u);
+                    const unsigned wd = philox_word((unsigned)(which ? lt_b2 : lt_b), which ? ut_b2 : ut_b, cls >> 2,
+                                                    (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
+                    noise[(tn & 1) * (BXT * 8) + b * 8 + (lane & 7u)] = gumbel_from_word(wd);
+                }
+            }
         };
         advance(0);
-        ps_barrier();                                                    // state of step 0 posted (wave 0 draws the noise of step 0)
+        draw_noise(0);
+        ps_barrier();                                                    // state and noise of step 0 posted
 
+        int x = NC / 2;
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
             __builtin_amdgcn_s_setprio(3);
             XD_STAMP(11, 0);
-            // ---- first look at the slot's 32 candidates (tag t): requested now, examined after the gsum reads below
-            const bool want_x = n_own > 0 && t > 0;
-            u64 g = 0;
-            if (want_x) g = ps_load(csrc);
+            // ---- cell update: gsum of step t-1 is complete (barrier B), x_{t-1} was picked up before it
             float s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
-            if (st_active && !st_first) {                                // gsum of step t-1 is complete: barrier B
+            if (st_active && !st_first) {
                 s0 = gsum[cb * 96 + cu]; s1 = gsum[cb * 96 + UPB + cu]; sn = gsum[cb * 96 + 2 * UPB + cu];
                 hold = hprev;
             }
             s0 += bq0; s1 += bq1; sn += bq2;
-            // ---- x_{t-1}
-            int x = NC / 2;
-            if (want_x) {
-                wt.start();
-                for (unsigned spins = 0;; ++spins) {
-                    if (__all(!cell_on || (unsigned)(g >> 40) == (unsigned)t)) break;
-                    if (wt.expired(spins, lane)) { *s_abort = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    g = ps_load(csrc);
-                }
-                // first argmax per half of 32 lanes (classes ascend with the rank): order-preserving integer image of the score
-                unsigned u = (unsigned)g;
-                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                unsigned m = u;
-                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));
-                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));
-                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));
-                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));
-                const unsigned m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 16),
-                               m2 = __builtin_amdgcn_readlane(m, 32), m3 = __builtin_amdgcn_readlane(m, 48);
-                const unsigned b01 = max(m0, m1), b23 = max(m2, m3);
-                const unsigned long long hit = __ballot(u == (lane < 32 ? b01 : b23));
-                const int f0 = __ffs((int)(unsigned)hit) - 1, f1 = __ffs((int)(unsigned)(hit >> 32)) - 1;
-                const int cls = (int)((g >> 32) & 255u);
-                const int x0 = __builtin_amdgcn_readlane(cls, f0 < 0 ? 0 : f0), x1 = __builtin_amdgcn_readlane(cls, 32 + (f1 < 0 ? 0 : f1));
-                x = lane < 32 ? x0 : x1;
-            }
-            XD_STAMP(11, 1);
-            // ---- embedding row, gates, publish h_t
             if (cell_on) {
                 float hn = 0.f;
                 if (st_active && cu < UPB) {
@@ -568,7 +592,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             XD_STAMP(11, 2);
             // ---- in the shadow of the h_t exchange: the sample x_{t-1} goes out (network_vocoder.py:78 output), the slot's state
-            // for step t + 1, the first phase of the fc1 weights
+            // and the noise for step t + 1, the first phase of the fc1 weights
             if (st_emit && cu == 0 && rank == (cb & 31)) {
                 if (p.wav) p.wav[(size_t)st_erow * p.Lout + st_eidx] = mtab[x];
                 if (p.mulaw) p.mulaw[(size_t)st_erow * p.Lout + st_eidx] = x;
@@ -599,8 +623,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             XD_STAMP(11, 5);
             XD_STAMP(10, 10);
-            // ---- W_hh rows 80..83 of the OTHER wave's slots, in the shadow of the a_t exchange: one chain pass, the lower half
-            // wave on slot 1 - sv, the upper half on slot 3 - sv
+            __builtin_amdgcn_s_setprio(1);
+            // ---- W_hh rows 80..83 of the OTHER wave's slots, behind the a_t exchange and the chain waves' fc2: one chain pass,
+            // the lower half wave on slot 1 - sv, the upper half on slot 3 - sv
             if (xb0 < bx) {
                 float4 wx0[8];
 #pragma unroll
@@ -612,63 +637,41 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             XD_STAMP(11, 7);
             XD_STAMP(10, 11);
-            // ---- a_t of the own slots, then fc2 + Gumbel-max candidate per slot
+            draw_noise(t + 1);                                           // idle time: the candidates are still on their way
+            // ---- x_t: the slot's 32 candidates (tag t + 1, from the chain waves' fc2), picked up BEFORE barrier B
+            __builtin_amdgcn_s_setprio(3);
             if (n_own > 0) {
-                float4 w2p[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) w2p[i] = wp2[i];
-                const float *nzp = noise + (t & 1) * (BXT * 8);
-                const float nz0 = nzp[sv * 8 + r8], nz1 = nzp[(sv + 2 < BXT ? sv + 2 : sv) * 8 + r8];
-                u64 va[2][4];
+                u64 g = 0;
                 wt.start();
                 for (unsigned spins = 0;; ++spins) {
-                    bool ok = true;
-                    if (sv + 2 < bx) gran_load8b<512 * BXT>(va, ga, ga + 128 * BXT, aoff);       // slots sv, sv + 2: ranks (lane >> 3) + 8 i
-                    else gran_load4b<512 * BXT>(va[0], ga, ga + 128 * BXT, aoff);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ok &= sv + 2 * q >= bx || (unsigned)(va[q][i] >> 32) == tag;
-                    if (__all(ok)) break;
+                    g = ps_load(csrc);
+                    if (__all(!cell_on || (unsigned)(g >> 40) == tag)) break;
                     if (wt.expired(spins, lane)) { *s_abort = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
                 }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int b = sv + 2 * q;
-                    if (b < bx) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ac[b * HF + 64 * i + adst] = __uint_as_float((unsigned)va[q][i]);
-                    }
-                }
-                XD_STAMP(11, 8);
-                float accq[2];
-                chain_lds2<NT_A>(wp2, w2p, opnd2 + sv * HF, opnd2 + (sv + 2 < BXT ? sv + 2 : sv) * HF, n_own > 1, accq[0], accq[1]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int b = sv + 2 * q;
-                    if (b >= bx) break;
-                    float v = chain_combine(accq[q]);
-                    v += b2;
-                    const float sc = v + (q ? nz1 : nz0);                    // classes 0..3 of the 8 in lanes 0..3, 4..7 in lanes 32..35
-                    float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 0));
-                    int kb = 0;
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) {
-                        const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), k < 4 ? k : 28 + k));
-                        if (sk > best) { best = sk; kb = k; }
-                    }
-                    const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
-                    if (lane == 0 && !drop)
-                        xd_put(gc, ((unsigned)rank * 16 + b) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
-                }
+                // first argmax per half of 32 lanes (classes ascend with the rank): order-preserving integer image of the score
+                unsigned u = (unsigned)g;
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                unsigned m = u;
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));
+                const unsigned m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 16),
+                               m2 = __builtin_amdgcn_readlane(m, 32), m3 = __builtin_amdgcn_readlane(m, 48);
+                const unsigned b01 = max(m0, m1), b23 = max(m2, m3);
+                const unsigned long long hit = __ballot(u == (lane < 32 ? b01 : b23));
+                const int f0 = __ffs((int)(unsigned)hit) - 1, f1 = __ffs((int)(unsigned)(hit >> 32)) - 1;
+                const int cls = (int)((g >> 32) & 255u);
+                const int x0 = __builtin_amdgcn_readlane(cls, f0 < 0 ? 0 : f0), x1 = __builtin_amdgcn_readlane(cls, 32 + (f1 < 0 ? 0 : f1));
+                x = lane < 32 ? x0 : x1;
             }
-            XD_STAMP(11, 9);
+            XD_STAMP(11, 1);
             __builtin_amdgcn_s_setprio(0);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
             if (*s_abort) break;
             XD_STAMP(11, 12);
         }
+        // ---- the last step's x has nowhere to go: every utterance ended at least one step before n_steps
     }
 #undef XD_SWEEP_H
 }
