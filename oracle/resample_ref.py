@@ -8,6 +8,9 @@ ratio.  resampy and librosa are not installed here and cannot be fetched: **pari
 constants below (64 zero crossings, precision 9, Kaiser beta 14.769656459379492, roll-off 0.9475937167399596) are
 resampy's published ``kaiser_best`` design, restated from its documentation -- they cannot be checked against the
 package's stored table offline.  Everything in float64, as resampy computes on librosa's float32 input upcast.
+Version assumption: the output clock follows resampy 0.2.2's interpolation loop (what librosa ^0.8 pins as >= 0.2.2), which
+advances the input time by SEQUENTIAL additions `time_register += time_increment` -- not `t * time_increment` as resampy >= 0.3's
+rewritten kernel does; the two differ in the last bits of the interpolation weights on long signals.
 """
 import numpy as np
 

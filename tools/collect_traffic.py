@@ -76,7 +76,7 @@ def main():
         return target(args.mode, args.utterances, args.codes)
 
     import bench                                   # kernel_source_sha(): imports torch, makes no GPU call
-    scratch = os.path.join(ROOT, "gpurun_out", "traffic")
+    scratch = os.path.join("/tmp", "vqcpc_traffic")
     os.makedirs(scratch, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     res = {}
