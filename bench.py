@@ -345,7 +345,7 @@ def run_convert_e2e(enc, voc, dev, n_utt, slots):
             "front_end_and_io_share": (front + back) / wall, "model_share": (tm.get("encode", 0.0) + tm.get("decode", 0.0)) / wall}
 
 
-def gru_roofline(voc, n_utt, step_us, n_steps=0):
+def gru_roofline(voc, n_utt, step_us, n_steps=0, samples_per_utt=0):
     """`roofline` object for the GRU-step kernel of the LAST generate() call: HIP events around 2000
     back-to-back launches on the launch stream (vqcpc_vocoder_kernel_times)."""
     step_tflops = FLOP_PER_SAMPLE * n_utt / (step_us * 1e-6) / 1e12
@@ -354,9 +354,11 @@ def gru_roofline(voc, n_utt, step_us, n_steps=0):
         # ONE launch for the whole call: eight resident decoders, one per XCD (csrc/ar_xcd.hip).  The launch IS the decode
         # loop, so its duration comes from the HIP events around it (vqcpc_vocoder_last_timing) and `achieved` prices every
         # sample of the launch with SURVEY 8d's 6 782 976 FLOP.
-        steps = max(int(n_steps), 1)
+        steps = max(int(n_steps), 1)                 # steps of the longest XCD (more utterances than slots run back to back)
+        per_utt = int(samples_per_utt) or steps
         launch_us = step_us * steps
-        flop = FLOP_PER_SAMPLE * n_utt * steps
+        flop = FLOP_PER_SAMPLE * n_utt * per_utt
+        step_tflops = flop / (launch_us * 1e-6) / 1e12
         return {"bound": "mfma",
                 "kernel": "ar_xcd_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD -- W_hh in VGPRs, fc1 / fc2 / "
                           "embedding table in LDS, h_t / a_t / candidates exchanged through the XCD's own L2; fp32 VALU fma chains, "
@@ -364,15 +366,15 @@ def gru_roofline(voc, n_utt, step_us, n_steps=0):
                 "achieved": step_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / FP32_PEAK_TFLOPS,
                 "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS,
                 "traffic": None, "flop_per_launch": flop, "avg_launch_us": launch_us, "utterances_per_launch": n_utt,
-                "samples_per_launch": n_utt * steps,
-                "algorithmic_bytes_per_launch": 4.0 * (8 * (GRU_MAC + 688128 + 229376 + 65536) + n_utt * steps) + 4.0 * n_utt * (steps // 160 + 1) * 2688,
+                "samples_per_launch": n_utt * per_utt,
+                "algorithmic_bytes_per_launch": 4.0 * (8 * (GRU_MAC + 688128 + 229376 + 65536) + n_utt * per_utt) + 4.0 * n_utt * (per_utt // 160 + 1) * 2688,
                 "how": "HIP events on the launch stream around the one launch of the call (vqcpc_vocoder_last_timing); flop = "
                        "6 782 976 per decoded sample x samples of the launch; algorithmic bytes = one copy of the recurrent weights "
                        "per XCD + the conditioning rows + the waveform",
-                "launches_per_sample": 1.0 / (n_utt * steps),
+                "launches_per_sample": 1.0 / (n_utt * per_utt),
                 "decode_step": {"us": step_us, "tflops": step_tflops, "frac": step_tflops / FP32_PEAK_TFLOPS,
-                                "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS, "flop": FLOP_PER_SAMPLE * n_utt,
-                                "how": "the launch's duration / samples per utterance; frac_executed leaves out the 688 128 MACs per "
+                                "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS, "flop": flop / steps,
+                                "how": "the launch's duration / steps of the longest XCD; frac_executed leaves out the 688 128 MACs per "
                                        "sample of the embedding half of W_ih, which is a table lookup on every path"}}
     try:
         gru_us, fc1_us, fc2_us, per_launch, kind = voc.kernel_times(2000)
@@ -522,7 +524,7 @@ def main():
     value = samples / dt
     loop_ms, n_loop = voc.last_timing()                       # HIP events around the last decode loop
     step_us = loop_ms * 1e3 / max(n_loop, 1)
-    roof = gru_roofline(voc, Bp, step_us, n_loop)
+    roof = gru_roofline(voc, Bp, step_us, n_loop, L)
     attach_traffic(roof)
 
     result = {
@@ -590,7 +592,7 @@ def main():
         step256()
         d256, _ = wall(step256, dev)
         ms256, n256_loop = voc.last_timing()
-        r256 = gru_roofline(voc, n256, ms256 * 1e3 / max(n256_loop, 1), n256_loop)
+        r256 = gru_roofline(voc, n256, ms256 * 1e3 / max(n256_loop, 1), n256_loop, L)
         r256["traffic_source"] = "none"
         result["one_gpu_256"] = {"workload": f"BASELINE configs[3] unsharded: {n256} utterances x {L} samples on one GPU "
                                              "(two tile groups of 128 on two streams)",
