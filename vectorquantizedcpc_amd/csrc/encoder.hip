@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256) void vq_encode_kernel(const float *__restrict_
 // activation traffic; per workgroup the stream is all 5 MB of weights (L2-resident: every workgroup reads the same).
 // ------------------------------------------------------------------------------------------
 #define FE_LD 514                       // LDS row stride of the activation tile: bank = 2 row + k, conflict-free A reads
+#define FE_WIN_C 128                    // channels of the staged mel window (the fused schedule runs for 4 C <= 512)
 
 __global__ void frag16_build_kernel(const float *__restrict__ W, int N, int K, float4 *__restrict__ Wf) {
     const int nq = K / 16;
@@ -712,6 +713,7 @@ __device__ __forceinline__ bool rows16_dump(const FusedP &p, const float *tile, 
 __global__ __launch_bounds__(512) void enc_fused_kernel(FusedP p) {
     __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
     __shared__ VqSmem sm;
+    __shared__ float mel_win[FE_WIN_C * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
     const int K0 = 4 * p.C;
     constexpr int NT = 4, RD = 4;                        // column tiles per wave; fragment ring: 3 q-steps ahead (a ring of 8 --
@@ -719,18 +721,41 @@ __global__ __launch_bounds__(512) void enc_fused_kernel(FusedP p) {
     float4 fr[RD][NT];
     rows16_prefetch<NT, RD>(p.conv_f, NT * wave, K0 / 16, fr, lane);      // the first conv fragments fly under the gather
 
-    // ---- im2col gather of the 16 rows (model.py:65), k order of the reference back end (fetch_a)
-    for (int e = tid; e < 16 * K0; e += 512) {
-        const int i = e & 15, kidx = e >> 4, m = r0 + i;
-        int c, tap;
-        if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
-        else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
-        float v = 0.f;
-        if (m < p.N) {
-            const int b = m / p.To, tt = m - b * p.To, ti = 2 * tt + tap - 1;
-            if (ti >= 0 && ti < p.T) v = p.mel[((size_t)b * p.C + c) * p.T + ti];
+    // ---- im2col of the 16 rows (model.py:65), k order of the reference back end (fetch_a).  When the 16 rows are consecutive
+    // frames of ONE utterance (always at configs[1]: 64 frames per utterance) their taps are a window of 34 mel frames per
+    // channel: it is loaded ONCE, coalesced along T (136 contiguous bytes per channel instead of 16 x 4 scalar loads 8 bytes
+    // apart), into LDS and the tile is built from there.  A tile that straddles two utterances (or the end) gathers from global.
+    const int b0 = r0 / p.To, tt0 = r0 - b0 * p.To;
+    const bool one_utt = r0 + 15 < p.N && tt0 + 15 < p.To && p.C <= FE_WIN_C;
+    if (one_utt) {
+        float *win = mel_win;                                 // [C][36]: frames 2 tt0 - 1 ... 2 tt0 + 32 (zero outside the utterance)
+        const float *src = p.mel + (size_t)b0 * p.C * p.T;
+        const int ti0 = 2 * tt0 - 1;
+        for (int e = tid; e < p.C * 36; e += 512) {
+            const int c = e / 36, o = e - c * 36, ti = ti0 + o;
+            win[e] = (o < 34 && ti >= 0 && ti < p.T) ? src[(size_t)c * p.T + ti] : 0.f;
         }
-        tile[i * FE_LD + kidx] = v;
+        __syncthreads();
+        for (int e = tid; e < 16 * K0; e += 512) {
+            const int i = e & 15, kidx = e >> 4;
+            int c, tap;
+            if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
+            else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
+            tile[i * FE_LD + kidx] = win[c * 36 + 2 * i + tap];
+        }
+    } else {
+        for (int e = tid; e < 16 * K0; e += 512) {
+            const int i = e & 15, kidx = e >> 4, m = r0 + i;
+            int c, tap;
+            if (p.conv_mode == 1) { c = kidx >> 2; tap = kidx & 3; }
+            else { const int rem = kidx & 63; tap = rem >> 4; c = (kidx >> 6) * 16 + (rem & 15); }
+            float v = 0.f;
+            if (m < p.N) {
+                const int b = m / p.To, tt = m - b * p.To, ti = 2 * tt + tap - 1;
+                if (ti >= 0 && ti < p.T) v = p.mel[((size_t)b * p.C + c) * p.T + ti];
+            }
+            tile[i * FE_LD + kidx] = v;
+        }
     }
     __syncthreads();
 
