@@ -75,15 +75,33 @@ __device__ __forceinline__ float ordered_val(unsigned k) {
 __global__ void mf_db_kernel(float *__restrict__ melraw, const int *__restrict__ len, int Tmax, int hop, int n_mels, int nmp,
                              unsigned *maxdb, size_t rows) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= rows * nmp) return;
-    const int m = (int)(id % nmp);
-    const size_t row = id / nmp;
-    const int n = (int)(row % Tmax), b = (int)(row / Tmax);
-    if (m >= n_mels || n >= 1 + len[b] / hop || len[b] < 2) return;
-    const float a = melraw[id];
-    const float l = 10.0f * log10f(fmaxf(1e-10f, a * a));      // amplitude_to_db(amin=1e-5, ref=1)
-    melraw[id] = l;
-    atomicMax(&maxdb[b], ordered_key(l));
+    bool valid = id < rows * nmp;
+    int b = -1;
+    unsigned key = 0u;
+    if (valid) {
+        const int m = (int)(id % nmp);
+        const size_t row = id / nmp;
+        const int n = (int)(row % Tmax);
+        b = (int)(row / Tmax);
+        valid = m < n_mels && n < 1 + len[b] / hop && len[b] >= 2;
+        if (valid) {
+            const float a = melraw[id];
+            const float l = 10.0f * log10f(fmaxf(1e-10f, a * a));      // amplitude_to_db(amin=1e-5, ref=1)
+            melraw[id] = l;
+            key = ordered_key(l);
+        }
+    }
+    // the utterance maximum: one atomic per wave instead of one per element (every element of a 2 s utterance hammering the
+    // same word took 8.5 ms per call: profiles/r03_bench_default_kernel_stats.csv) -- a wave almost always covers one utterance
+    const unsigned long long act = __ballot(valid);
+    if (act == 0ull) return;
+    const int first = __ffsll((long long)act) - 1;
+    const int b0 = __shfl(b, first);
+    if (__all(!valid || b == b0)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, off));
+        if ((int)(threadIdx.x & 63) == first) atomicMax(&maxdb[b0], key);
+    } else if (valid) atomicMax(&maxdb[b], key);
 }
 
 __global__ void mf_final_kernel(const float *__restrict__ melraw, const int *__restrict__ len, const unsigned *__restrict__ maxdb,
