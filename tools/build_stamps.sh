@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 DEF=${1:--DVQCPC_XD_STAMPS}
 mkdir -p build/stamps
-for f in encoder vocoder ar_xcd melfront loudness resample; do
+for f in encoder vocoder ar_xcd ar_xcm melfront loudness resample; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $DEF -c vectorquantizedcpc_amd/csrc/$f.hip -o build/stamps/$f.o &
 done
 wait

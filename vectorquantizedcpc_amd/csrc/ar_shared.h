@@ -58,3 +58,31 @@ __device__ __forceinline__ void ps_load_weights(const float *Wrow, int kw, int c
 }
 
 #define PS_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
+
+// ---- in-kernel exchanges of the resident decoders (ar_xcd.hip, ar_xcm.hip): 8-byte {tag, value} granules -- the data is the
+// flag.  Published with a store addressed as (uniform 64-bit base in SGPRs) + (32-bit byte offset in a VGPR): workgroup scope
+// (sc0: the write-through L1 leaves the granule in this XCD's L2) or agent scope (sc1).  hipcc does not pad the hazard between
+// a VALU write of the base SGPRs (v_readfirstlane) and a vector-memory instruction inside an asm statement reading them:
+// every such statement opens with the five wait states itself.
+__device__ __forceinline__ void xd_put(u64 *base, unsigned byte_off, u64 v, int agent) {
+    if (agent) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" :: "v"(byte_off), "v"(v), "s"(base) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc0" :: "v"(byte_off), "v"(v), "s"(base) : "memory");   // stays in this XCD's L2
+}
+
+struct Waiter {                      // bounded spinning shared by all sweeps of the kernel
+    unsigned *status;
+    unsigned ticks;
+    u64 t0;
+    // The wall clock (s_memrealtime: a scalar memory read, ~0.3 us) is only consulted once a wait has spun 64 times: a wait
+    // that succeeds quickly never pays for it.  t0 = 0: not taken yet.
+    __device__ __forceinline__ void start() { t0 = 0; }
+    // true: give up (deadline passed -- status bit 0 is then set -- or somebody else already gave up)
+    __device__ __forceinline__ bool expired(unsigned spins, int lane) {
+        if ((spins & 63) != 63) return false;
+        const u64 now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) t0 = now;
+        const bool late = now - t0 > (u64)ticks;
+        if (late && lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // host-mapped: a plain store, no PCIe atomic
+        return late || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
+    }
+};

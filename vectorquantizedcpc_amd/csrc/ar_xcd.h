@@ -34,3 +34,9 @@ size_t xd_exchange_bytes(int bxt);
 bool xd_supported(int Hr, int Hf, int n_cls);
 int xd_pick_bxt(int slots_per_xcd);            // 1, 2, 4 (0: too many)
 int xd_launch(const XdParams &p, hipStream_t s);
+
+// The same decoders for large batches (ar_xcm.hip): 16 decode slots per XCD on the matrix cores.  Same XdParams (bxt is
+// ignored: the layout is fixed at XM_BX slots per XCD), same schedule table, same status word.
+#define XM_BX 16
+size_t xm_exchange_bytes();
+int xm_launch(const XdParams &p, hipStream_t s);

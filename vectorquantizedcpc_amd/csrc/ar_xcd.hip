@@ -73,10 +73,6 @@ constexpr int CTL_WORDS = 64;          // u32: arrivals per XCC [0..7], total [8
 // the memory operations of an asm statement, so the wait is part of it; nor does it pad the hazard between a VALU write of
 // the base SGPRs (v_readfirstlane) and a vector-memory instruction inside the statement reading them: every statement
 // opens with the five wait states itself -- without them the stamped build and the 2-slot instantiation faulted).
-__device__ __forceinline__ void xd_put(u64 *base, unsigned byte_off, u64 v, int agent) {
-    if (agent) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" :: "v"(byte_off), "v"(v), "s"(base) : "memory");
-    else asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc0" :: "v"(byte_off), "v"(v), "s"(base) : "memory");   // stays in this XCD's L2
-}
 template <int STEP>
 __device__ __forceinline__ void gran_load1(u64 (&v)[1], const u64 *base, unsigned off) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(off), "s"(base) : "memory");
@@ -266,20 +262,6 @@ __device__ __forceinline__ int chain_pos(int NS, int k) {
     const int q = (k >> 2) & 3, c0 = k & 1, ci = (k >> 1) & 1;
     return (2 * kw + c0) * (8 * NS) + 8 * s + 4 * ci + q;
 }
-
-struct Waiter {                      // bounded spinning shared by all sweeps of the kernel
-    unsigned *status;
-    unsigned ticks;
-    u64 t0;
-    __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memrealtime(); }
-    // true: give up (deadline passed -- status bit 0 is then set -- or somebody else already gave up)
-    __device__ __forceinline__ bool expired(unsigned spins, int lane) {
-        if ((spins & 63) != 63) return false;
-        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (u64)ticks;
-        if (late && lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // host-mapped: a plain store, no PCIe atomic
-        return late || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
-    }
-};
 
 // LDS carve, in floats (ints behind them)
 template <int BXT> struct Lds {

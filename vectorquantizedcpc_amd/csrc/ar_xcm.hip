@@ -1,0 +1,588 @@
+// ar_xcm.hip -- the per-XCD resident decoders of ar_xcd.hip for LARGE batches: 16 decode slots per XCD (128 per GPU) on
+// the matrix cores (network_vocoder.py:78's sample loop; RNN_MS spec: DESIGN.md 2.2).
+//
+// Same partition as ar_xcd.hip: decode slot s lives on XCD s % 8; each XCD runs its own copy of the recurrence on its 32 CUs
+// with a full copy of the weights held ON the CUs; workgroup `rank` owns hidden units 28 rank .. + 27 (84 gate rows of W_hh),
+// 8 rows of fc1 and 8 classes of fc2.  What changes is how a row meets the state: the 84 + 8 rows (+ 4 of padding) are six
+// 16-row tiles of v_mfma_f32_16x16x4_f32 against the 16 slots' h_t -- [W_hh; W_fc1] h_t is ONE product, fc1 rides along --
+// with the A fragments of a (tile, K half) pinned in the 112 VGPRs of one wave (12 waves = 6 tiles x 2 K halves), so that,
+// as in ar_xcd.hip, no weight is fetched again after the prologue (the launch-per-step kernel this replaces pulls 172 KB
+// of W_hh into every workgroup at every sample step).  The arithmetic is the launch kernels': a row's dot product is the
+// same 8 fp32 fma chains (K quarter x x/z | y/w accumulator, ar_shared.h), combined ((q0 + q1) + q2) + q3.
+//
+// A sample step (all 16 slots of the XCD together):
+//   all waves     cell update of the 28 owned units x 16 slots (thread = (unit, slot)) from the previous step's row sums
+//                 -> h_t published; h_t of all 32 workgroups swept into LDS                               -> barrier A
+//   all waves     112 MFMAs each: [W_hh; W_fc1] h_t partial sums of the wave's tile and K half -> LDS
+//   waves 5, 11   (tile 5 = W_hh rows 80..83 + the 8 fc1 rows; high priority, so they are through first) fc1 + ReLU ->
+//                 a_t published; slot bookkeeping, conditioning rows and Gumbel noise of step t + 1 in the shadow of
+//                 that exchange; a_t swept (each wave its K half); fc2 on the matrix pipe (A fragments from LDS);
+//                 Gumbel-max candidate of the 8 owned classes per slot published; the 32 candidates per slot swept,
+//                 x_t = their first argmax; the sample goes out; the embedding rows of x_t fetched for the next cell
+//                 update                                                                                -> barrier B
+// Exchanges are the 8-byte {tag, value} granules of ar_xcd.hip, two per 16-byte load, laid out so that every sweep reads
+// a linear array.  Every wait is wall-clock bounded (status bit 0, vqcpc_vocoder_check); placement is checked as there.
+#include "ar_xcd.h"
+#include "ar_shared.h"
+
+// Timeline stamps of worker 5 of XCD 0 (100 MHz wall clock), steps 256..383, for tools/xcm_timeline.py: compiled in only
+// with -DVQCPC_XD_STAMPS (a debug build under build/stamps/, never the shipped library).
+#ifdef VQCPC_XD_STAMPS
+__device__ unsigned long long g_xm_stamps[128 * 24];
+#define XM_STAMP(wv, i) do { if (rank == 5 && xcc == 0 && wave == (wv) && (threadIdx.x & 63u) == 0 && t >= 256 && t < 384) \
+        g_xm_stamps[(t - 256) * 24 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int vqcpc_debug_xm_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xm_stamps), sizeof(g_xm_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define XM_STAMP(wv, i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int HR = 896, HF = 256, NC = 256;
+constexpr int NW = 32;                 // workgroups per XCD
+constexpr int UPB = 28;                // hidden units per workgroup
+constexpr int FPB = 8;                 // fc1 rows / fc2 classes per workgroup
+constexpr int THREADS = 768;
+constexpr int BX = XM_BX;              // decode slots per XCD = columns of an MFMA tile
+constexpr int LROWS = 96;              // rows of a workgroup: 84 of W_hh [gate][unit], 8 of fc1, 4 of padding
+constexpr int HSD = HR + 4;            // slot stride of h_t in LDS (floats): 16 slots x 16 bytes hit 64 different banks
+constexpr int ASD = HF + 4;
+constexpr int CELLS = UPB * BX;        // cell-update threads: (unit, slot)
+constexpr int BOOK = 11;               // the wave that keeps the slots' books (the youngest: it has nothing else to do behind its MFMAs)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// exchange area of one XCD, in granules
+constexpr int XM_H = HR * BX;          // [column = 28 rank + unit][slot]
+constexpr int XM_A = HF * BX;          // [row = 8 rank + f][slot]
+constexpr int XM_C = BX * NW;          // [slot][rank]
+constexpr int XM_REGION = XM_H + XM_A + XM_C;
+constexpr int CTL_WORDS = 64;          // u32: arrivals per XCC [0..7], total [8]
+
+// LDS carve, in floats (ints behind them)
+struct Lds {
+    static constexpr int hT = 0;                          // [BX][HSD]   h_t
+    static constexpr int aT = hT + BX * HSD;              // [BX][ASD]   a_t
+    static constexpr int f2a = aT + BX * ASD;             // [16 blocks][64 lanes][4]  fc2 A fragments (8 classes + 8 zero rows)
+    static constexpr int part = f2a + 16 * 64 * 4;        // [3][LROWS][BX]  q0 + q1 | q2 | q3 of every row
+    static constexpr int fcx = part + 3 * LROWS * BX;     // [2][16][BX]  fc2: q2 | q3 from wave 11
+    static constexpr int gcl = fcx + 2 * 16 * BX;         // [BX][84]  conditioning rows in use [gate][unit]
+    static constexpr int noise = gcl + BX * 84;           // [2][BX][8]
+    static constexpr int mtab = noise + 2 * BX * 8;       // [NC]
+    static constexpr int sinfo = mtab + NC;               // int [2][BX][8] {active, first, lt, utt, row, frame to load or -1}
+    static constexpr int xs = sinfo + 2 * BX * 8;         // int [BX]  x_t
+    static constexpr int segst = xs + BX;                 // int [BX][8] {index, row, t0, len, utt, samples into / index of the conditioning frame}
+    static constexpr int bqs = segst + BX * 8;            // [3][32] b_hh of the owned units, then b_fc1 [8], b_fc2 [8] of the owned rows
+    static constexpr int ctl = bqs + 112;                   // int [8] {xcc, rank, ok, abort, and three wave 5 <-> wave 11 flags: fc1 sums, fc2 sums, bookkeeping}
+    static constexpr int total = ctl + 12;
+};
+
+// five 16-byte chunks (two granules each) at byte offset `off` from five uniform bases, all in flight together; sc1: served by
+// L2.  (The bases are SGPR pairs: see ar_shared.h for the wait states in front.)
+__device__ __forceinline__ void chunks5(u32x4 (&v)[5], const u64 *b0, const u64 *b1, const u64 *b2, const u64 *b3, const u64 *b4, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %5, %6 sc1\n\tglobal_load_dwordx4 %1, %5, %7 sc1\n\tglobal_load_dwordx4 %2, %5, %8 sc1\n\t"
+                 "global_load_dwordx4 %3, %5, %9 sc1\n\tglobal_load_dwordx4 %4, %5, %10 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                 : "v"(off), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4) : "memory");
+}
+// eight chunks 1 KB apart from two bases 4 KB apart
+__device__ __forceinline__ void chunks8(u32x4 (&v)[8], const u64 *b, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %8, %9 sc1\n\tglobal_load_dwordx4 %1, %8, %9 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, %9 offset:2048 sc1\n\tglobal_load_dwordx4 %3, %8, %9 offset:3072 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, %10 sc1\n\tglobal_load_dwordx4 %5, %8, %10 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, %10 offset:2048 sc1\n\tglobal_load_dwordx4 %7, %8, %10 offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(off), "s"(b), "s"(b + 512) : "memory");
+}
+// three chunks from three uniform bases
+__device__ __forceinline__ void chunks3(u32x4 (&v)[3], const u64 *b0, const u64 *b1, const u64 *b2, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %5 sc1\n\tglobal_load_dwordx4 %2, %3, %6 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(off), "s"(b0), "s"(b1), "s"(b2) : "memory");
+}
+// four chunks 1 KB apart from one base
+__device__ __forceinline__ void chunks4(u32x4 (&v)[4], const u64 *b, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 sc1\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(b) : "memory");
+}
+__device__ __forceinline__ void chunks2(u32x4 (&v)[2], const u64 *b, unsigned off0, unsigned off1) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(off0), "v"(off1), "s"(b) : "memory");
+}
+
+// max / min over the 16 lanes of a DPP row, result in all of them
+__device__ __forceinline__ unsigned row_max(unsigned m) {
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));     // row_half_mirror
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));     // row_mirror
+    return m;
+}
+__device__ __forceinline__ unsigned row_min(unsigned m) {
+    m = min(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));
+    m = min(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));
+    m = min(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));
+    m = min(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));
+    return m;
+}
+__device__ __forceinline__ unsigned ordered(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }     // order-preserving image of a float
+
+// A value the optimiser must recompute behind this point: the sample loop keeps 112 weight registers per lane for the whole
+// call, and every loop-invariant address hipcc hoists out of it (it finds dozens) is spilled to scratch.  Each phase of a
+// step derives its addressing from an opaque copy of the thread index instead.
+__device__ __forceinline__ unsigned opq(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+
+#define XM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *hT = smem + Lds::hT, *aT = smem + Lds::aT, *f2a = smem + Lds::f2a, *part = smem + Lds::part, *fcx = smem + Lds::fcx;
+    float *gcl = smem + Lds::gcl, *noise = smem + Lds::noise, *mtab = smem + Lds::mtab;
+    int *sinfo = (int *)(smem + Lds::sinfo), *xs = (int *)(smem + Lds::xs), *s_ctl = (int *)(smem + Lds::ctl), *segst = (int *)(smem + Lds::segst);
+    float *bqs = smem + Lds::bqs;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+
+    // ---- placement: which XCD am I on, which of its 32 workers am I?  (as ar_xcd.hip)
+    if (tid == 0) {
+        unsigned xid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+        xid &= 7u;
+        unsigned *ctl = (unsigned *)p.xg;
+        const unsigned r = __hip_atomic_fetch_add(ctl + xid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0; __hip_atomic_load(ctl + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+            if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > (u64)p.timeout_ticks ||
+                                       __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (ok)
+            for (int x = 0; x < 8; ++x)
+                if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
+        if (!ok) __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = 0; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_ctl[9] = 0;
+    }
+    __syncthreads();
+    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[0]), rank = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    if (__builtin_amdgcn_readfirstlane(s_ctl[2]) == 0) return;
+    int bx = (p.n_slots - xcc + 7) / 8;                // slots of this XCD: xcc, xcc + 8, ...
+    bx = bx < 0 ? 0 : (bx > BX ? BX : bx);
+    const int n_steps = p.n_steps[xcc];
+    if (bx == 0 || n_steps <= 0) return;
+    const int agent = p.agent_stores;
+
+    u64 *gh = p.xg + CTL_WORDS / 2 + (size_t)xcc * XM_REGION;
+    u64 *ga = gh + XM_H, *gc = ga + XM_A;
+
+    // ---- this wave's tile and K half; its A fragments: registers for the whole call
+    // The SIMD's instruction arbiter serves its OLDEST wave first (measured: of three waves in the same MFMA loop the lowest
+    // wave id gets through at the single-wave rate, the next one after it, the youngest last: 2.5 / 4.2 / 5.4 us; and a young
+    // wave doing ordinary work next to older waves in their MFMA loop gets next to no issue slots: ~30 instructions took up
+    // to 2.7 us; s_setprio changes neither).  So tile 5 -- W_hh rows 80..83 + the 8 fc1 rows + padding, on which everything
+    // that is serial in a step hangs (fc1 -> a_t -> fc2 -> draw -> x_t) -- belongs to waves 0 and 1, the oldest of their SIMDs:
+    // they are through their MFMAs first and keep the issue priority for the serial path while the others multiply.
+    const bool fcw = wave < 2;
+    const int tl = fcw ? 5 : (wave - 2) % 5, kh = fcw ? wave : (wave - 2) / 5;
+    const unsigned arow = lane & 15u, aq = lane >> 4;
+    float wr[112];
+    {
+        const int lr = 16 * tl + (int)arow;
+        const float *Wrow = lr < 84 ? p.w_hh + (size_t)((lr / UPB) * HR + UPB * rank + lr % UPB) * HR
+                          : lr < 92 ? p.w_fc1 + (size_t)(FPB * rank + lr - 84) * HR : nullptr;
+#pragma unroll
+        for (int b = 0; b < 28; ++b) {                                 // 16-column block 28 kh + b: K quarter 2 kh + b / 14, super-step b % 14
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (Wrow) v = *(const float4 *)(Wrow + 16 * (28 * kh + b) + 4 * aq);
+            wr[4 * b] = v.x; wr[4 * b + 1] = v.y; wr[4 * b + 2] = v.z; wr[4 * b + 3] = v.w;
+        }
+    }
+
+    // ---- resident LDS state
+    for (unsigned e = tid; e < 16 * 64 * 4; e += THREADS) {
+        const unsigned blk = e >> 8, ln = (e >> 2) & 63u, comp = e & 3u, row = ln & 15u, qq = ln >> 4;
+        f2a[e] = row < FPB ? p.w_fc2[(size_t)(FPB * rank + row) * HF + 16 * blk + 4 * qq + comp] : 0.f;
+    }
+    for (unsigned e = tid; e < NC; e += THREADS) mtab[e] = p.mulaw_tab[e];
+    for (unsigned e = tid; e < 3 * LROWS * BX; e += THREADS) part[e] = 0.f;
+    for (unsigned e = tid; e < BX * 84; e += THREADS) gcl[e] = 0.f;
+    for (unsigned e = tid; e < 2 * BX * 8; e += THREADS) sinfo[e] = 0;
+    for (unsigned e = tid; e < BX; e += THREADS) xs[e] = NC / 2;
+    __syncthreads();
+
+    Waiter wt{p.status, p.timeout_ticks, 0};
+    int *s_abort = s_ctl + 3;
+
+    for (unsigned e = tid; e < 96; e += THREADS) { const unsigned g = e >> 5, u = e & 31u; bqs[e] = u < UPB ? p.b_hh[g * HR + UPB * rank + u] : 0.f; }
+    for (unsigned e = tid; e < 16; e += THREADS) bqs[96 + e] = e < 8 ? p.b_fc1[FPB * rank + e] : p.b_fc2[FPB * rank + e - 8];
+    for (unsigned e = tid; e < BX; e += THREADS) {
+        const XdSeg sg = (int)e < bx ? p.segs[(size_t)(xcc + 8 * e) * p.max_seg] : XdSeg{-1, 0, 0, 0u};
+        int *st = segst + e * 8;
+        st[0] = 0; st[1] = sg.len > 0 ? sg.row : -1; st[2] = sg.t0; st[3] = sg.len; st[4] = (int)sg.utt; st[5] = 0; st[6] = 0;
+    }
+    __syncthreads();
+
+    // ---- slot bookkeeping (lane b < 16 of wave 5 = slot b; the segment state lives in LDS): what step `tn` needs that does
+    // not depend on the data: sinfo[tn & 1][slot] = {active, first, lt, utt, row, conditioning frame to load or -1}
+    auto advance = [&](int tn, unsigned ln) {
+        if (ln >= (unsigned)BX) return;
+        int *st = segst + ln * 8;
+        int sg_i = st[0], sg_row = st[1], sg_t0 = st[2], sg_len = st[3], sg_fpos = st[5], sg_fidx = st[6];
+        unsigned sg_utt = (unsigned)st[4];
+        int lt = tn - sg_t0;
+        if (sg_row >= 0 && lt >= sg_len) {                        // next utterance of this slot
+            sg_i += 1;
+            XdSeg sg = XdSeg{-1, 0, 0, 0u};
+            if (sg_i < p.max_seg) sg = p.segs[(size_t)(xcc + 8 * ln) * p.max_seg + sg_i];
+            sg_row = sg.len > 0 ? sg.row : -1; sg_t0 = sg.t0; sg_len = sg.len; sg_utt = sg.utt;
+            lt = tn - sg_t0;
+            sg_fpos = 0; sg_fidx = 0;
+            st[0] = sg_i; st[1] = sg_row; st[2] = sg_t0; st[3] = sg_len; st[4] = (int)sg_utt;
+        }
+        const bool active = sg_row >= 0 && lt >= 0 && lt < sg_len;
+        int frame = -1;
+        if (active) {
+            if (sg_fpos == p.upsample) { sg_fpos = 0; sg_fidx += 1; }
+            if (sg_fpos == 0) frame = sg_fidx < p.F ? sg_fidx : p.F - 1;      // next conditioning frame (once per hop)
+            sg_fpos += 1;
+        }
+        st[5] = sg_fpos; st[6] = sg_fidx;
+        int *si = sinfo + ((tn & 1) * BX + (int)ln) * 8;
+        si[0] = active ? 1 : 0; si[1] = lt == 0 ? 1 : 0; si[2] = lt; si[3] = (int)sg_utt; si[4] = sg_row; si[5] = frame;
+    };
+    // conditioning rows of the slots that enter a new frame at step tn, and the Gumbel noise of that step's draw (wave 5)
+    auto prepare = [&](int tn, unsigned ln) {
+        const int *sn = sinfo + (tn & 1) * BX * 8;
+        unsigned long long fresh = __ballot(ln < (unsigned)bx && sn[(ln & 15u) * 8 + 5] >= 0);       // slots entering a new frame (once per hop each)
+        while (fresh) {
+            const int b = __ffsll((long long)fresh) - 1;
+            fresh &= fresh - 1;
+            const int f = sn[b * 8 + 5], row = sn[b * 8 + 4];
+            for (unsigned e = ln; e < 84; e += 64) {
+                const unsigned g = e / UPB, u = e - g * UPB;
+                gcl[b * 84 + e] = p.Gcond[((size_t)row * p.F + f) * 3 * HR + g * HR + UPB * rank + u];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = (int)(ln >> 3) + 8 * h;
+            if (b < bx) {
+                const unsigned cls = FPB * rank + (ln & 7u);
+                const unsigned wd = philox_word((unsigned)sn[b * 8 + 2], (unsigned)sn[b * 8 + 3], cls >> 2, (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
+                noise[((tn & 1) * BX + b) * 8 + (ln & 7u)] = gumbel_from_word(wd);
+            }
+        }
+    };
+    // LDS hand-offs inside the workgroup are ordered by construction: one wave's LDS instructions are performed in order, so a
+    // flag written after the data is seen after the data, and a read issued after the flag was seen sees the data.  A
+    // release fence would also wait for the wave's outstanding global stores (published granules, samples going out to HBM):
+    // ~1 us, on the critical path.  So: relaxed accesses, lgkmcnt waits, and the compiler kept from reordering.
+    auto lds_fence = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto xm_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto aborted = [&]() { return __hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+    // wave 0 <-> wave 1 hand-offs through an LDS word
+    auto flag_set = [&](int which, unsigned tag, unsigned ln) {
+        asm volatile("" ::: "memory");
+        if (ln == 0) __hip_atomic_store(s_ctl + which, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto flag_wait = [&](int which, unsigned tag, unsigned ln) {
+        wt.start();
+        for (unsigned spins = 0; __hip_atomic_load(s_ctl + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tag; ++spins)
+            if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+        asm volatile("" ::: "memory");
+    };
+
+    if (wave == BOOK) { advance(0, lane); lds_fence(); prepare(0, lane); }
+    ps_barrier();
+
+    float hprev = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f;     // cell threads: h_{t-1} of (unit, slot); embedding rows of x_{t-1}
+    for (int t = 0; t < n_steps; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        // ---- cell update (nn.GRU cell of RNN_MS): thread (unit cu, slot cs); row sums of step t - 1 from LDS
+        XM_STAMP(0, 0); XM_STAMP(2, 12);
+        {
+            const unsigned td = opq(tid);
+            if (td < (unsigned)CELLS) {
+                const unsigned cu = td >> 4, cs = td & 15u;
+                const int *si = sinfo + ((t & 1) * BX + (int)cs) * 8;
+                const bool active = (int)cs < bx && si[0] != 0, first = si[1] != 0;
+                // the embedding rows of the sample fed in were requested before barrier B; an utterance's first step takes class NC / 2
+                if (active && first) {
+                    const float *gp = p.Gemb + (size_t)(NC / 2) * 3 * HR + UPB * rank + cu;
+                    e0 = gp[0]; e1 = gp[HR]; e2 = gp[2 * HR];
+                }
+                float s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
+                if (active && !first) {
+                    const float *pp = part + cu * BX + cs;
+                    s0 = (pp[0] + pp[LROWS * BX]) + pp[2 * LROWS * BX];
+                    s1 = (pp[UPB * BX] + pp[(LROWS + UPB) * BX]) + pp[(2 * LROWS + UPB) * BX];
+                    sn = (pp[2 * UPB * BX] + pp[(LROWS + 2 * UPB) * BX]) + pp[(2 * LROWS + 2 * UPB) * BX];
+                    hold = hprev;
+                }
+                s0 += bqs[cu]; s1 += bqs[32 + cu]; sn += bqs[64 + cu];
+                float hn = 0.f;
+                if (active) {
+                    const float *cp = gcl + cs * 84 + cu;
+                    const float r = sigmoidf_((e0 + cp[0]) + s0);
+                    const float z = sigmoidf_((e1 + cp[UPB]) + s1);
+                    const float nn = tanhf((e2 + cp[2 * UPB]) + r * sn);
+                    hn = (1.0f - z) * nn + z * hold;
+                    hprev = hn;
+                }
+                xd_put(gh, ((unsigned)(UPB * rank + cu) * BX + cs) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
+            }
+        }
+        XM_STAMP(0, 1);
+        // ---- h_t of all 32 workers: 7168 16-byte chunks (column, slot pair), a linear array; ten per thread in two rounds (all
+        // ten in flight together would need 40 registers next to the 112 weights: measured, spills)
+#pragma unroll 1
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const unsigned td = opq(tid);
+            u32x4 v[5];
+            const u64 *b0 = gh + (size_t)(5 * rnd) * 1536;
+            wt.start();
+            for (unsigned spins = 0;; ++spins) {
+                chunks5(v, b0, b0 + 1536, b0 + 2 * 1536, b0 + 3 * 1536, b0 + 4 * 1536, td * 16u);
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) ok &= (td + 768u * (5 * rnd + i) >= (unsigned)(XM_H / 2)) || (v[i].y == tag && v[i].w == tag);
+                if (__all(ok)) break;
+                if (wt.expired(spins, (int)(td & 63u))) { *s_abort = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const unsigned L = td + 768u * (5 * rnd + i);
+                if (L < (unsigned)(XM_H / 2)) {
+                    const unsigned k = L >> 3, pr = L & 7u;
+                    hT[(2 * pr) * HSD + k] = __uint_as_float(v[i].x);
+                    hT[(2 * pr + 1) * HSD + k] = __uint_as_float(v[i].z);
+                }
+            }
+        }
+        XM_STAMP(0, 2); XM_STAMP(2, 13);
+        xm_barrier();                                                // A: h_t in LDS
+        if (*s_abort) break;
+        XM_STAMP(0, 3); XM_STAMP(2, 14);
+
+        // ---- [W_hh; W_fc1] h_t: 28 blocks of 16 columns, four MFMAs each (x, z -> accumulator 0; y, w -> accumulator 1 of the K quarter)
+        v4f qa, qb;                                                  // q_(2 kh), q_(2 kh + 1): D fragment, register i of lane (aq, arow) = row 4 aq + i of the tile, slot arow
+        {
+            const unsigned ln = opq(lane);
+            const float4 *hb = (const float4 *)(hT + (ln & 15u) * HSD + 448 * kh + 4 * (ln >> 4));     // B fragments: h_t[slot][16 (28 kh + b) + 4 aq ..]
+            v4f acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+            float4 q[3];
+            q[0] = hb[0]; q[1] = hb[4];
+#pragma unroll
+            for (int b = 0; b < 28; ++b) {
+                if (b + 2 < 28) q[(b + 2) % 3] = hb[4 * (b + 2)];
+                const float4 hv = q[b % 3];
+                const int kwl = b / 14;
+                acc[kwl][0] = XM_MFMA(wr[4 * b + 0], hv.x, acc[kwl][0]);
+                acc[kwl][1] = XM_MFMA(wr[4 * b + 1], hv.y, acc[kwl][1]);
+                acc[kwl][0] = XM_MFMA(wr[4 * b + 2], hv.z, acc[kwl][0]);
+                acc[kwl][1] = XM_MFMA(wr[4 * b + 3], hv.w, acc[kwl][1]);
+            }
+            qa = acc[0][0] + acc[0][1]; qb = acc[1][0] + acc[1][1];
+        }
+        XM_STAMP(0, 4); XM_STAMP(2, 15); XM_STAMP(1, 16);
+        v4f p01 = qa + qb;                                           // meaningful in the kh = 0 waves
+#ifdef VQCPC_XD_STAMPS
+        asm volatile("" : "+v"(p01));
+        XM_STAMP(0, 22); XM_STAMP(1, 23);
+#endif
+        {
+            const unsigned ln = opq(lane);
+            float *pw = part + (16 * tl + 4 * (ln >> 4)) * BX + (ln & 15u);
+            if (kh == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[i * BX] = p01[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pw[(LROWS + i) * BX] = qa[i]; pw[(2 * LROWS + i) * BX] = qb[i]; }
+            }
+        }
+        if (wave == BOOK) {
+            // ---- bookkeeping, conditioning rows and Gumbel noise of step t + 1
+            const unsigned ln = opq(lane);
+            advance(t + 1, ln);
+            lds_fence();
+            prepare(t + 1, ln);
+        }
+        if (fcw) {
+            // ================================================================  waves 0 and 1: everything behind fc1
+            if (kh == 1) { flag_set(4, tag, opq(lane)); XM_STAMP(1, 19); }
+            else {
+                // ---- fc1 + ReLU -> a_t published: tile rows 4..11 = fc1 rows 0..7 (lanes aq = 1, 2)
+                const unsigned ln = opq(lane), aq = ln >> 4, arow = ln & 15u;
+                flag_wait(4, tag, ln);
+                XM_STAMP(0, 18);
+                if (aq == 1 || aq == 2) {
+                    const float *pr = part + (80 + 4 * aq) * BX + arow;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int f = 4 * ((int)aq - 1) + i;
+                        float v = (p01[i] + pr[(LROWS + i) * BX]) + pr[(2 * LROWS + i) * BX];
+                        v += bqs[96 + f];
+                        v = v > 0.f ? v : 0.f;
+                        xd_put(ga, ((unsigned)(FPB * rank + f) * BX + arow) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
+                    }
+                }
+                XM_STAMP(0, 5);
+            }
+            // ---- a_t: this wave's K half = rows 128 kh .. + 127 of all 16 slots: 1024 chunks, 16 per lane in two rounds
+#pragma unroll 1
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                const unsigned ln = opq(lane);
+                u32x4 v[8];
+                const u64 *b0 = ga + (size_t)(128 * kh) * BX + (size_t)rnd * 1024;
+                wt.start();
+                for (unsigned spins = 0;; ++spins) {
+                    chunks8(v, b0, ln * 16u);
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ok &= v[i].y == tag && v[i].w == tag;
+                    if (__all(ok)) break;
+                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned c = ln + 64u * i + 512u * rnd;
+                    const unsigned r = 128u * kh + (c >> 3), pr = c & 7u;
+                    aT[(2 * pr) * ASD + r] = __uint_as_float(v[i].x);
+                    aT[(2 * pr + 1) * ASD + r] = __uint_as_float(v[i].z);
+                }
+            }
+            XM_STAMP(0, 6);
+            XM_STAMP(0, 7);
+            // ---- fc2 on the matrix pipe: 8 blocks of 16 columns of this wave's K half; rows 0..7 = the owned classes
+            v4f fa, fb;
+            {
+                const unsigned ln = opq(lane);
+                v4f a2[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+                const float4 *ab = (const float4 *)(aT + (ln & 15u) * ASD + 128 * kh + 4 * (ln >> 4));
+                const float4 *wb = (const float4 *)f2a + (8 * kh) * 64 + ln;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const float4 av = ab[4 * b], wv = wb[64 * b];
+                    const int kwl = b / 4;
+                    a2[kwl][0] = XM_MFMA(wv.x, av.x, a2[kwl][0]);
+                    a2[kwl][1] = XM_MFMA(wv.y, av.y, a2[kwl][1]);
+                    a2[kwl][0] = XM_MFMA(wv.z, av.z, a2[kwl][0]);
+                    a2[kwl][1] = XM_MFMA(wv.w, av.w, a2[kwl][1]);
+                }
+                fa = a2[0][0] + a2[0][1]; fb = a2[1][0] + a2[1][1];
+            }
+            XM_STAMP(0, 20);
+            {
+                const unsigned ln = opq(lane), aq = ln >> 4, arow = ln & 15u;
+                if (kh == 1) {
+                    if (aq < 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { fcx[(4 * aq + i) * BX + arow] = fa[i]; fcx[(16 + 4 * aq + i) * BX + arow] = fb[i]; }
+                    }
+                    flag_set(5, tag, ln);
+                } else {
+                    flag_wait(5, tag, ln);
+                    XM_STAMP(0, 21);
+                    // ---- Gumbel-max candidate of the 8 owned classes for slot arow: lanes aq = 0 (classes 0..3), 1 (4..7)
+                    float best = 0.f;
+                    int kb = 0;
+                    if (aq < 2) {
+                        const v4f f01 = fa + fb;
+                        const float *nz = noise + ((t & 1) * BX + arow) * 8 + 4 * aq;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = (f01[i] + fcx[(4 * aq + i) * BX + arow]) + fcx[(16 + 4 * aq + i) * BX + arow];
+                            v += bqs[104 + 4 * aq + i];
+                            const float sc = v + nz[i];
+                            if (i == 0 || sc > best) { best = sc; kb = 4 * (int)aq + i; }
+                        }
+                    }
+                    const float ob = __shfl(best, (int)ln + 16);
+                    const int ok2 = __shfl(kb, (int)ln + 16);
+                    if (ob > best) { best = ob; kb = ok2; }                  // lanes 0..15: first maximum over the 8 classes
+                    const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
+                    if (ln < (unsigned)BX && !drop)
+                        xd_put(gc, (ln * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                }
+            }
+            XM_STAMP(0, 8);
+            // ---- x_t: the 32 candidates of a slot = 16 chunks = one DPP row; two slot groups per wave
+            {
+                const unsigned ln = opq(lane);
+                const int *si = sinfo + (t & 1) * BX * 8;
+                u32x4 v[2];
+                const unsigned c0 = (kh ? 64u : 0u) + ln, c1 = c0 + 128u;           // chunk = slot * 16 + rank pair
+                wt.start();
+                for (unsigned spins = 0;; ++spins) {
+                    chunks2(v, gc, c0 * 16u, c1 * 16u);
+                    const bool ok = (v[0].y >> 8) == tag && (v[0].w >> 8) == tag && (v[1].y >> 8) == tag && (v[1].w >> 8) == tag;
+                    if (__all(ok)) break;
+                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned u0 = ordered(v[h].x), u1 = ordered(v[h].z);
+                    const unsigned u = u1 > u0 ? u1 : u0;                 // classes ascend with the rank: the first maximum wins
+                    const unsigned cl = (u1 > u0 ? v[h].w : v[h].y) & 255u;
+                    const unsigned m = row_max(u);
+                    const unsigned x = row_min(u == m ? cl : 0xFFFFu);
+                    const int b = (int)((h ? c1 : c0) >> 4);
+                    if ((ln & 15u) == 0 && b < bx) {
+                        xs[b] = (int)x;
+                        if (si[b * 8 + 0] && rank == (b & 31)) {          // the sample goes out (network_vocoder.py:78 output)
+                            const size_t at = (size_t)si[b * 8 + 4] * p.Lout + si[b * 8 + 2];
+                            if (p.wav) p.wav[at] = mtab[x];
+                            if (p.mulaw) p.mulaw[at] = (int64_t)x;
+                        }
+                    }
+                }
+                lds_fence();
+                if (ln == 0) __hip_atomic_fetch_add(s_ctl + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // x_t of this wave's slots is in LDS
+                XM_STAMP(0, 9);
+            }
+            XM_STAMP(0, 10); XM_STAMP(1, 17);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- the embedding rows of x_t, requested before barrier B (both fc waves have posted their slots' x_t: word 7 counts
+        // them) and used by the next cell update; an utterance's first step takes class NC / 2 instead (decided behind the barrier)
+        if (tid < (unsigned)CELLS) {
+            const unsigned td = opq(tid), cu = td >> 4, cs = td & 15u;
+            wt.start();
+            for (unsigned spins = 0; __hip_atomic_load(s_ctl + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 * (int)tag; ++spins) {
+                if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            asm volatile("" ::: "memory");
+            const float *gp = p.Gemb + (size_t)xs[cs] * 3 * HR + UPB * rank + cu;
+            e0 = gp[0]; e1 = gp[HR]; e2 = gp[2 * HR];
+        }
+        xm_barrier();                                                // B: row sums, x_t, step t + 1's bookkeeping in LDS
+        if (*s_abort) break;
+    }
+}
+
+}  // namespace
+
+size_t xm_exchange_bytes() { return (size_t)CTL_WORDS * 4 + (size_t)8 * XM_REGION * sizeof(u64); }
+
+int xm_launch(const XdParams &p, hipStream_t s) {
+    static bool attr = false;
+    constexpr size_t lds = sizeof(float) * (size_t)Lds::total;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    VQ_REQUIRE(p.n_slots >= 1 && p.n_slots <= 8 * XM_BX, "xm_launch: %d slots do not fit 8 x %d", p.n_slots, XM_BX);
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)ar_xcm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    HIP_TRY(hipMemsetAsync(p.xg, 0, xm_exchange_bytes(), s));
+    hipLaunchKernelGGL(ar_xcm_kernel, dim3(8 * NW), dim3(THREADS), lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return VQCPC_OK;
+}

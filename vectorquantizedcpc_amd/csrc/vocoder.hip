@@ -1606,8 +1606,15 @@ struct vqcpc_vocoder {
     int xcd_agent_stores = 0;            // tests / A-B: publish with agent-scope stores
     int xcd_timeout_ms = 250;            // bound of its in-kernel waits
     int xcd_debug_drop_step = -1;        // tests: one worker skips a candidate publish at this step -> the waits time out
+    // the same decoders on the matrix cores, 16 slots per XCD (ar_xcm.hip): -1 auto (more than xcm_min and fewer than xcm_max
+    // utterances in flight), 0 never, 1 whenever the dimensions allow.  Measured (tools/xcm_probe.py, bench_by_batch): 11.3 us
+    // per step whatever the number of slots in use -> 5.7 M samples/s at 64 utterances (VALU form through 32 slots: 6.5 M),
+    // 11.2 M at 128 and 256 (launches: 8.2 / 10.8 M), against 12.5 M on the launch path with 512 utterances in flight.
+    int xcm = -1;
+    int xcm_min = 75, xcm_max = 384;
+    int xcm_slots = 8 * XM_BX;
     DevBuf xd_x, xd_segs;                // exchange area, slot schedule
-    bool last_was_xcd = false;
+    bool last_was_xcd = false, last_was_xcm = false;
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
@@ -1808,6 +1815,26 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         return VQCPC_OK;
     }
     if (!strcmp(name, "xcd_agent_stores")) { v->xcd_agent_stores = value != 0; return VQCPC_OK; }
+    if (!strcmp(name, "xcm")) {
+        VQ_REQUIRE(value >= -1 && value <= 1, "xcm must be -1 (auto), 0 or 1");
+        v->xcm = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcm_min")) {
+        VQ_REQUIRE(value >= 0 && value <= 65536, "xcm_min out of range");
+        v->xcm_min = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcm_max")) {
+        VQ_REQUIRE(value >= 0 && value <= (1 << 20), "xcm_max out of range");
+        v->xcm_max = value;
+        return VQCPC_OK;
+    }
+    if (!strcmp(name, "xcm_slots")) {
+        VQ_REQUIRE(value >= 1 && value <= 8 * XM_BX, "xcm_slots must be in [1, %d]", 8 * XM_BX);
+        v->xcm_slots = value;
+        return VQCPC_OK;
+    }
     if (!strcmp(name, "xcd_timeout_ms")) {
         VQ_REQUIRE(value >= 1 && value <= 10000, "xcd_timeout_ms must be in [1, 10000]");
         v->xcd_timeout_ms = value;
@@ -1852,7 +1879,7 @@ static int persist_check(vqcpc_vocoder *v) {
 
 extern "C" int vqcpc_vocoder_last_path(vqcpc_vocoder *v) {
     if (!v) return -1;
-    return v->last_was_xcd ? 2 : (v->have_last ? 0 : 1);
+    return v->last_was_xcm ? 3 : v->last_was_xcd ? 2 : (v->have_last ? 0 : 1);
 }
 
 extern "C" int vqcpc_vocoder_check(vqcpc_vocoder *v) {
@@ -2068,7 +2095,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // upload through the pinned arena: no synchronisation of the caller's stream
     TRY(v->stage.begin(lens.size() * sizeof(int) + (table[0].size() + table[1].size()) * sizeof(ArSlot) +
                        (size_t)(tiles[0] + tiles[1]) * 16 * sizeof(ArSlot) + 2 * sizeof(ArCall) + 256 +
-                       (size_t)8 * XD_MAX_BX * (B + 1) * sizeof(XdSeg)));
+                       (size_t)8 * XM_BX * (B + 1) * sizeof(XdSeg)));
     TRY(v->stage.upload(v->len.p, lens.data(), lens.size() * sizeof(int), s));
     for (int g = 0; g < n_grp; ++g) {
         TRY(v->stage.upload(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), s));
@@ -2088,18 +2115,22 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev_ptr, v->abort_host, 0));
     // One resident, weight-stationary decoder per XCD (ar_xcd.hip): utterances dealt over the XCDs' decode slots, longest
     // first onto the slot that frees up first; a slot runs its utterances back to back (no replay boundaries here).
-    v->last_was_xcd = false;
+    v->last_was_xcd = false; v->last_was_xcm = false;
     int nz = 0;                               // utterances that produce samples
     for (int b = 0; b < B; ++b) nz += lens[Bp + b] > 0;
-    // auto: up to 64 utterances in flight (measured: 5.2 M samples/s through its 32 slots at 32 and 64 utterances against 3.4 /
-    // 4.7 M on the launch path; from 96 on the large-batch launches win: 6.5 M at 96, 8.4 M at 128, 10.9 M at 256)
+    // auto: up to xcm_min (75) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
+    // against 3.4 / 4.7 M on the launch path), from there to xcm_max the matrix-core form through its 128 slots, above that the
+    // launch-per-step kernels
     const int in_flight = v->n_slots > 0 && v->n_slots < nz ? v->n_slots : nz;
-    const bool xcd_wanted = v->xcd == 1 || (v->xcd == -1 && in_flight <= 64);
+    // the matrix-core form (16 slots per XCD) takes over from xcm_min utterances in flight; `xcd` = 0 turns both off, = 1 asks for
+    // the VALU form whatever the count
+    const bool xcm_wanted = v->xcd != 0 && (v->xcm == 1 || (v->xcm == -1 && v->xcd == -1 && in_flight > v->xcm_min && in_flight < v->xcm_max));
+    const bool xcd_wanted = xcm_wanted || v->xcd == 1 || (v->xcd == -1 && in_flight <= v->xcm_min);
     if (xcd_wanted && !inputs && xd_supported(Hr, d.Hf, d.n_cls) && max_t > 0 && max_t < (1 << 24) && nz > 0) {
-        int xs = v->xcd_slots < 1 ? 1 : v->xcd_slots;
+        int xs = xcm_wanted ? v->xcm_slots : (v->xcd_slots < 1 ? 1 : v->xcd_slots);
         if (v->n_slots > 0 && v->n_slots < xs) xs = v->n_slots;
         if (nz < xs) xs = nz;
-        const int bxt = xd_pick_bxt((xs + 7) / 8);
+        const int bxt = xcm_wanted ? XM_BX : xd_pick_bxt((xs + 7) / 8);
         std::vector<long> xend(xs, 0);
         std::vector<std::vector<XdSeg>> lists(xs);
         for (int row : order) {
@@ -2123,7 +2154,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         }
         VQ_REQUIRE(bxt > 0 && longest < (1L << 24), "vocoder: per-XCD schedule out of range");
         TRY(v->xd_segs.reserve(tab.size() * sizeof(XdSeg)));
-        TRY(v->xd_x.reserve(xd_exchange_bytes(bxt)));
+        TRY(v->xd_x.reserve(xcm_wanted ? xm_exchange_bytes() : xd_exchange_bytes(bxt)));
         TRY(v->stage.upload(v->xd_segs.p, tab.data(), tab.size() * sizeof(XdSeg), s));
         xp.w_hh = v->w_hh; xp.w_fc1 = v->w_fc1; xp.b_fc1 = v->b_fc1; xp.w_fc2 = v->w_fc2; xp.b_fc2 = v->b_fc2;
         xp.Gemb = v->Gemb; xp.b_hh = v->b_hh; xp.Gcond = v->gcond.as<float>(); xp.mulaw_tab = v->mulaw_tab;
@@ -2132,12 +2163,12 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         xp.Lout = Lout; xp.F = T2; xp.upsample = d.upsample_t; xp.agent_stores = v->xcd_agent_stores;
         xp.timeout_ticks = (unsigned)v->xcd_timeout_ms * 100000u; xp.dbg_drop_step = v->xcd_debug_drop_step;
         HIP_TRY(hipEventRecord(v->ev0, s));
-        TRY(xd_launch(xp, s));
+        TRY(xcm_wanted ? xm_launch(xp, s) : xd_launch(xp, s));
         HIP_TRY(hipEventRecord(v->ev1, s));
         v->last_steps = (int)longest;
         v->have_last = false;
         v->persist_pending = true;
-        v->last_was_xcd = true;
+        v->last_was_xcd = !xcm_wanted; v->last_was_xcm = xcm_wanted;
         return VQCPC_OK;
     }
     // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
