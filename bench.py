@@ -53,7 +53,8 @@ FLOP_PER_FRAME = 2555904        # encoder, per output frame without the LSTM (SU
 GRU_MAC = 2408448               # W_hh MACs per sample: the dominant kernel's algorithmic work
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 KERNEL_SOURCES = ("vectorquantizedcpc_amd/csrc/vocoder.hip", "vectorquantizedcpc_amd/csrc/ar_xcd.hip",
-                  "vectorquantizedcpc_amd/csrc/ar_shared.h", "vectorquantizedcpc_amd/csrc/common.h")
+                  "vectorquantizedcpc_amd/csrc/ar_xcm.hip", "vectorquantizedcpc_amd/csrc/ar_shared.h",
+                  "vectorquantizedcpc_amd/csrc/common.h")
 
 
 def log(msg):
@@ -350,8 +351,10 @@ def gru_roofline(voc, n_utt, step_us, n_steps=0, samples_per_utt=0):
     back-to-back launches on the launch stream (vqcpc_vocoder_kernel_times)."""
     step_tflops = FLOP_PER_SAMPLE * n_utt / (step_us * 1e-6) / 1e12
     exec_frac = FLOP_EXECUTED_PER_SAMPLE / FLOP_PER_SAMPLE
-    if voc.last_path() == 2:
-        # ONE launch for the whole call: eight resident decoders, one per XCD (csrc/ar_xcd.hip).  The launch IS the decode
+    path = voc.last_path()
+    if path in (2, 3):
+        # ONE launch for the whole call: eight resident decoders, one per XCD (csrc/ar_xcd.hip; csrc/ar_xcm.hip from 76
+        # utterances in flight: 16 slots per XCD on the matrix cores).  The launch IS the decode
         # loop, so its duration comes from the HIP events around it (vqcpc_vocoder_last_timing) and `achieved` prices every
         # sample of the launch with SURVEY 8d's 6 782 976 FLOP.
         steps = max(int(n_steps), 1)                 # steps of the longest XCD (more utterances than slots run back to back)
@@ -360,9 +363,12 @@ def gru_roofline(voc, n_utt, step_us, n_steps=0, samples_per_utt=0):
         flop = FLOP_PER_SAMPLE * n_utt * per_utt
         step_tflops = flop / (launch_us * 1e-6) / 1e12
         return {"bound": "mfma",
-                "kernel": "ar_xcd_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD -- W_hh in VGPRs, fc1 / fc2 / "
-                          "embedding table in LDS, h_t / a_t / candidates exchanged through the XCD's own L2; fp32 VALU fma chains, "
-                          "bit-identical to the MFMA kernels)",
+                "kernel": ("ar_xcd_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD -- W_hh in VGPRs, fc1 / fc2 / "
+                           "embedding table in LDS, h_t / a_t / candidates exchanged through the XCD's own L2; fp32 VALU fma chains, "
+                           "bit-identical to the MFMA kernels)") if path == 2 else
+                          ("ar_xcm_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD for 16 decode slots -- "
+                           "[W_hh; W_fc1] h_t as six v_mfma_f32_16x16x4_f32 tiles per workgroup with the A fragments pinned in VGPRs, "
+                           "fc2 fragments in LDS, h_t / a_t / candidates exchanged through the XCD's own L2)"),
                 "achieved": step_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / FP32_PEAK_TFLOPS,
                 "frac_executed": step_tflops * exec_frac / FP32_PEAK_TFLOPS,
                 "traffic": None, "flop_per_launch": flop, "avg_launch_us": launch_us, "utterances_per_launch": n_utt,
@@ -432,7 +438,7 @@ def attach_traffic(roof):
     if roof.get("avg_launch_us") is None or pmc.get("utterances") != roof["utterances_per_launch"]:
         roof["traffic_source"] = "offline file covers another batch size"
         return
-    if ("ar_xcd" in pmc.get("kernel", "")) != ("ar_xcd" in roof["kernel"]):
+    if any((k in pmc.get("kernel", "")) != (k in roof["kernel"]) for k in ("ar_xcd", "ar_xcm")):
         roof["traffic_source"] = "offline file covers another kernel"
         return
     roof["traffic"] = pmc["traffic_bytes_per_launch"]
@@ -594,8 +600,9 @@ def main():
         ms256, n256_loop = voc.last_timing()
         r256 = gru_roofline(voc, n256, ms256 * 1e3 / max(n256_loop, 1), n256_loop, L)
         r256["traffic_source"] = "none"
-        result["one_gpu_256"] = {"workload": f"BASELINE configs[3] unsharded: {n256} utterances x {L} samples on one GPU "
-                                             "(two tile groups of 128 on two streams)",
+        how256 = {3: "(continuous batching through the 128 decode slots of the matrix-core per-XCD decoders)",
+                  2: "(continuous batching through the 32 decode slots of the per-XCD decoders)"}.get(voc.last_path(), "(two tile groups of 128 on two streams)")
+        result["one_gpu_256"] = {"workload": f"BASELINE configs[3] unsharded: {n256} utterances x {L} samples on one GPU " + how256,
                                  "samples_per_s": n256 * L / d256, "realtime_factor_16k": n256 * L / 16000.0 / d256,
                                  "ms_per_step": d256 * 1e3, "roofline": r256}
         del mel256
