@@ -38,18 +38,18 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 32]:
     s = np.array(buf, dtype=np.int64).reshape(128, 16) * 0.01     # us
     a, b = s[4:120], s[5:121]
     rows = [
-        ("wave 11: past barrier B -> own h_t published (gsum reads, cell update)", a[:, 2] - a[:, 0]),
-        ("wave 11: h published -> h_t of all 32 workers gathered (+ sample out, next state, noise)", a[:, 3] - a[:, 2]),
+        ("service wave 0: past barrier B -> own h_t published (gsum reads, cell update)", a[:, 2] - a[:, 0]),
+        ("service wave 0: h published -> h_t of all 32 workers gathered (+ sample out, next state, noise)", a[:, 3] - a[:, 2]),
         ("barrier A", a[:, 4] - a[:, 3]),
-        ("wave 11: barrier A -> fc1 rows of its slots published", a[:, 5] - a[:, 4]),
-        ("wave 10: barrier A -> fc1 rows of its slots published", a[:, 10] - a[:, 4]),
-        ("wave 11: fc1 published -> W_hh rows 80..83 of the other wave's slots done", a[:, 7] - a[:, 5]),
-        ("wave 10: fc1 published -> W_hh rows 80..83 of the other wave's slots done", a[:, 11] - a[:, 10]),
-        ("wave 0: barrier A -> a_t of its slot gathered (after its first W_hh chains)", a[:, 8] - a[:, 4]),
-        ("wave 0: a_t gathered -> candidate published (fc2 + draw)", a[:, 9] - a[:, 8]),
-        ("wave 0: candidate published -> all its W_hh chains done", a[:, 6] - a[:, 9]),
-        ("wave 11: W_hh rows done -> x_t known (candidate sweep + argmax)", a[:, 1] - a[:, 7]),
-        ("wave 11: x_t known -> past barrier B", a[:, 12] - a[:, 1]),
+        ("service wave 0: barrier A -> fc1 rows of its slots published", a[:, 5] - a[:, 4]),
+        ("service wave 1: barrier A -> fc1 rows of its slots published", a[:, 10] - a[:, 4]),
+        ("service wave 0: fc1 published -> W_hh rows 80..83 of the other wave's slots done", a[:, 7] - a[:, 5]),
+        ("service wave 1: fc1 published -> W_hh rows 80..83 of the other wave's slots done", a[:, 11] - a[:, 10]),
+        ("chain wave 0: barrier A -> a_t of its slot gathered (after its first W_hh chains)", a[:, 8] - a[:, 4]),
+        ("chain wave 0: a_t gathered -> candidate published (fc2 + draw)", a[:, 9] - a[:, 8]),
+        ("chain wave 0: candidate published -> all its W_hh chains done", a[:, 6] - a[:, 9]),
+        ("service wave 0: W_hh rows done -> x_t known (candidate sweep + argmax)", a[:, 1] - a[:, 7]),
+        ("service wave 0: x_t known -> past barrier B", a[:, 12] - a[:, 1]),
         ("whole step", b[:, 0] - a[:, 0]),
     ]
     print(f"per-XCD decoders, {B} utterance(s): {ms * 1e3 / n:.2f} us per sample step over the call; worker 5 of XCD 0, "

@@ -19,11 +19,14 @@
 // share its operand values (each lane loads a quarter of h from LDS, v_fmac_f32_dpp quad_perm broadcasts them), which
 // cuts the LDS operand traffic by 4 and leaves the step VALU-bound.
 //
-// Roles of the 12 waves of a workgroup:
-//   waves 0..9   W_hh h_t chains of rows 0..79 for every slot of the XCD (8 rows per wave, weights pinned in VGPRs) -> gsum
-//   wave b < bx  also: sweep of a_t of slot b, fc2 + Gumbel-max candidate of the 8 owned classes -> publish (between its W_hh
-//                chains: one slot per wave, in parallel)
-//   wave 11 / 10 what else is serial in a sample step, for the even / odd slots: cell update of the 28 owned units; publish
+// Roles of the 12 waves of a workgroup (the two service waves are waves 0 and 1, the OLDEST of their SIMDs: the instruction
+// arbiter serves the oldest wave first -- ar_xcm.hip has the measurements -- and what they do is the critical path; as waves
+// 11 / 10 the single-utterance step took 2.90 us, as waves 0 / 1 it takes 2.82):
+//   waves 2..11  (chain waves 0..9) W_hh h_t chains of rows 0..79 for every slot of the XCD (8 rows per wave, weights pinned
+//                in VGPRs) -> gsum
+//   chain wave b < bx  also: sweep of a_t of slot b, fc2 + Gumbel-max candidate of the 8 owned classes -> publish (between its
+//                W_hh chains: one slot per wave, in parallel)
+//   wave 0 / 1   what else is serial in a sample step, for the even / odd slots: cell update of the 28 owned units; publish
 //                h_t; the slot's state for the next step in the shadow of the h_t exchange; fc1 (weights streamed from LDS)
 //                -> publish a_t; W_hh rows 80..83 for the OTHER wave's slots (one chain pass: a half wave per slot); the
 //                next step's Gumbel noise (Philox + two logs per class); x_t from the slot's 32 candidates, picked up
@@ -391,9 +394,10 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     } while (0)
 
     const float *opnd = hc + cid * NT_H + 8 * j;
-    if (wave < 10) {
+    if (wave >= 2) {
+        const int cw = wave - 2;                                           // chain wave 0..9
         // =====================================================================================  chain waves: W_hh rows 0..79
-        const unsigned row_local = 8 * wave + r8;                          // gate * UPB + unit
+        const unsigned row_local = 8 * cw + r8;                          // gate * UPB + unit
         float w[NT_H];
         {
             const unsigned gate = row_local / UPB, ul = row_local - gate * UPB;
@@ -401,11 +405,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         }
         // wave b < bx also runs fc2 + the draw of slot b (one slot per wave, in parallel), between its W_hh chains: a_t of the
         // slot arrives while the first chains run
-        const bool fc2_wave = wave < bx;
+        const bool fc2_wave = cw < bx;
         const int fc2_after = bx < 3 ? bx : 3;                             // chains done before it looks for a_t
         const float b2 = p.b_fc2[FPB * rank + r8];
         const float4 *wp2 = (const float4 *)(fc2w + (r8 * 8 + cid) * NT_A);
-        const float *opnd2 = ac + wave * HF + cid * NT_A + 8 * j;
+        const float *opnd2 = ac + cw * HF + cid * NT_A + 8 * j;
         ps_barrier();                                                      // state and noise of step 0 posted
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
@@ -418,10 +422,10 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 if (sum_lane) gsum[b * 96 + row_local] = v;
                 if (fc2_wave && b + 1 == fc2_after) {
                     // ---- a_t of slot `wave` (256 granules, 4 per lane) -> fc2 -> Gumbel-max candidate of the 8 owned classes
-                    const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)wave) << 3) + (lane & 7u)) * 8u;
+                    const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
                     const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);
                     float4 wa = wp2[0], wb = wp2[1];                     // first weights and the noise: on their way during the sweep
-                    const float nz = noise[(t & 1) * (BXT * 8) + wave * 8 + r8];
+                    const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8];
                     u64 va[4];
                     wt.start();
                     for (unsigned spins = 0;; ++spins) {
@@ -433,8 +437,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                         if (wt.expired(spins, lane)) { *s_abort = 1; break; }
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ac[wave * HF + 64 * i + adst] = __uint_as_float((unsigned)va[i]);
-                    XD_STAMP(0, 8);
+                    for (int i = 0; i < 4; ++i) ac[cw * HF + 64 * i + adst] = __uint_as_float((unsigned)va[i]);
+                    XD_STAMP(2, 8);
                     const float4 a0 = ((const float4 *)opnd2)[0], a1 = ((const float4 *)opnd2)[1];
                     const float hv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                     float acc2 = 0.f;
@@ -461,21 +465,21 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     }
                     const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
                     if (lane == 0 && !drop)
-                        xd_put(gc, ((unsigned)rank * 16 + wave) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
-                    XD_STAMP(0, 9);
+                        xd_put(gc, ((unsigned)rank * 16 + cw) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                    XD_STAMP(2, 9);
                 }
             }
-            XD_STAMP(0, 6);
+            XD_STAMP(2, 6);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
             if (*s_abort) break;
         }
     } else {
         // =====================================================================================  service waves
-        // Wave 11 (sv 0) owns the even slots of the XCD, wave 10 (sv 1) the odd ones, for what is serial in a sample step
+        // Wave 0 (sv 0) owns the even slots of the XCD, wave 1 (sv 1) the odd ones, for what is serial in a sample step
         // and not a chain wave's: x_{t-1} from the slot's 32 candidates, the cell update of the 28 owned units, h_t
         // published, fc1 -> a_t published; and, behind those, W_hh rows 80..83 for the OTHER wave's slots and the next
         // step's Gumbel noise.  Half wave hw of the cell update takes slot sv + 2 hw.
-        const int sv = 11 - wave;
+        const int sv = wave;
         const int hw = (int)(lane >> 5);
         const int cb = sv + 2 * hw;                                     // slot of this half wave in the cell update
         const unsigned cu = lane & 31u;                                 // unit
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
             __builtin_amdgcn_s_setprio(3);
-            XD_STAMP(11, 0);
+            XD_STAMP(0, 0);
             // ---- cell update: gsum of step t-1 is complete (barrier B), x_{t-1} was picked up before it
             float s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
             if (st_active && !st_first) {
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 }
                 if (cu < UPB) xd_put(gh, (((unsigned)(rank * BXT + cb) << 5) + cu) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
             }
-            XD_STAMP(11, 2);
+            XD_STAMP(0, 2);
             // ---- in the shadow of the h_t exchange: the sample x_{t-1} goes out (network_vocoder.py:78 output), the slot's state
             // and the noise for step t + 1, the first phase of the fc1 weights
             if (st_emit && cu == 0 && rank == (cb & 31)) {
@@ -584,10 +588,10 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) w1p[i] = wp1[i];
             XD_SWEEP_H();
-            XD_STAMP(11, 3);
+            XD_STAMP(0, 3);
             ps_barrier();                                                // A: h_t in LDS
             if (*s_abort) break;
-            XD_STAMP(11, 4);
+            XD_STAMP(0, 4);
             // ---- fc1 of the own slots (both together: every weight is used for both and then dropped)
             if (n_own > 0) {
                 float accA, accB;
@@ -603,8 +607,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     if (sum_lane) xd_put(ga, (((unsigned)(rank * BXT + sv + 2) << 3) + r8) * 8u, ((u64)tag << 32) | __float_as_uint(v2), agent);
                 }
             }
-            XD_STAMP(11, 5);
-            XD_STAMP(10, 10);
+            XD_STAMP(0, 5);
+            XD_STAMP(1, 10);
             __builtin_amdgcn_s_setprio(1);
             // ---- W_hh rows 80..83 of the OTHER wave's slots, behind the a_t exchange and the chain waves' fc2: one chain pass,
             // the lower half wave on slot 1 - sv, the upper half on slot 3 - sv
@@ -617,8 +621,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 const float v = chain_combine(acc);
                 if (sum_lane && (lane < 32 || x_two)) gsum[xslot * 96 + 80 + (r8 & 3u)] = v;
             }
-            XD_STAMP(11, 7);
-            XD_STAMP(10, 11);
+            XD_STAMP(0, 7);
+            XD_STAMP(1, 11);
             draw_noise(t + 1);                                           // idle time: the candidates are still on their way
             // ---- x_t: the slot's 32 candidates (tag t + 1, from the chain waves' fc2), picked up BEFORE barrier B
             __builtin_amdgcn_s_setprio(3);
@@ -647,11 +651,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 const int x0 = __builtin_amdgcn_readlane(cls, f0 < 0 ? 0 : f0), x1 = __builtin_amdgcn_readlane(cls, 32 + (f1 < 0 ? 0 : f1));
                 x = lane < 32 ? x0 : x1;
             }
-            XD_STAMP(11, 1);
+            XD_STAMP(0, 1);
             __builtin_amdgcn_s_setprio(0);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
             if (*s_abort) break;
-            XD_STAMP(11, 12);
+            XD_STAMP(0, 12);
         }
         // ---- the last step's x has nowhere to go: every utterance ended at least one step before n_steps
     }
