@@ -222,11 +222,17 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * and the GRU step of sample t share ONE launch -- W_hh h does not depend on the drawn sample, so it runs while the fc2
  * workgroups of the same launch produce the candidates, which the GRU's gate waves then pick up through 8-byte granules.
  * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) aborts like `persistent`.
- * xcd (default -1 = auto, 0 never, 1 whenever the dimensions are the reference's): generate() runs as EIGHT resident,
+ * xcd (default -1 = auto: up to xcm_min utterances in flight; 0 never, also turns xcm off; 1 whenever the dimensions are
+ * the reference's): generate() runs as EIGHT resident,
  * weight-stationary decoders, one per XCD (ar_xcd.hip): decode slot s lives on XCD s % 8; each XCD keeps a full copy of the
  * recurrent weights on its 32 CUs (W_hh in VGPRs, fc1 / fc2 / the sample-embedding table in LDS) and exchanges h_t, a_t and
  * the draw candidates through its own L2; no launches per sample.  Same samples as every other path.  xcd_slots: decode
  * slots it may use (default and maximum 32); more utterances than slots run back to back in them (longest first).
+ * xcm (default -1 = auto: more than xcm_min (75) and fewer than xcm_max (384) utterances in flight; 0 never; 1 whenever the
+ * dimensions are the reference's): the same resident decoders with 16 decode slots per XCD on the matrix cores
+ * (ar_xcm.hip): [W_hh; W_fc1] h_t as six v_mfma_f32_16x16x4_f32 tiles per workgroup, A fragments pinned in registers.
+ * xcm_slots: decode slots it may use (default and maximum 128).  Same samples as every other path; shares xcd's timeout,
+ * debug-drop and agent-store options and its status word.
  * xcd_agent_stores / xcd_timeout_ms / xcd_debug_drop_step, handoff_timeout_ms / handoff_debug_drop_step: A-B and tests
  * of the abort path (one worker skips a publish at that step; the waits give up after the timeout; vqcpc_vocoder_check).
  * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
@@ -249,7 +255,7 @@ int vqcpc_vocoder_check(vqcpc_vocoder *voc);
 
 /* Which decode loop the last generate()/logits() call on the handle ran (measurement and tests; the samples do not depend
  * on it): 0 = launch-per-step kernels, 1 = the 64-workgroup persistent single-utterance decoder, 2 = the per-XCD resident
- * decoders; -1 = null handle. */
+ * decoders, 3 = their matrix-core form (16 slots per XCD); -1 = null handle. */
 int vqcpc_vocoder_last_path(vqcpc_vocoder *voc);
 
 /* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM-side traffic per launch of the dominant decode kernel, from rocprofv3 PMC counters (GPU box only).
 
-    python3 tools/collect_traffic.py [--utterances 32] [--mode xcd|graph16|eager]
+    python3 tools/collect_traffic.py [--utterances 32] [--mode xcd|xcm|graph16|eager]
 
 Runs separate `rocprofv3 --pmc` passes (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum TCC_MISS_sum -- they do not fit one pass,
 MI355X_MICROARCH.md "rocprofv3 PMC slots") over a short decode of `--utterances` concurrent utterances and writes
@@ -10,7 +10,7 @@ profiles/r02_pmc_traffic.json: per-launch averages of the GRU-step kernel, the g
 (a file measured on other kernel sources is refused there).
 
 Launch mode: `xcd` (default) = the per-XCD resident decoders, ONE launch per call (csrc/ar_xcd.hip), measured on a call of
-`--codes` codes per utterance (default 25 = 8 000 samples); `graph16` replays the per-sample kernels from a hipGraph of 16 steps (the shipped path, shorter replay);
+`--codes` codes per utterance (default 25 = 8 000 samples); `xcm` = their matrix-core form (csrc/ar_xcm.hip, 16 slots per XCD), measured the same way; `graph16` replays the per-sample kernels from a hipGraph of 16 steps (the shipped path, shorter replay);
 `eager` launches the same kernels one by one.  The shipped 160-step replay cannot be profiled with --pmc on ROCm 7.2:
 rocprofiler-sdk faults in its packet interceptor when the HSA intercept queue overflows (DESIGN.md "Measurement").
 The parent process never touches the GPU; each pass is a fresh child under rocprofv3.
@@ -37,6 +37,8 @@ def target(mode, n_utt, codes):
     voc = voc.cuda().eval()
     if mode == "xcd":
         voc.set_option("xcd", 1)
+    elif mode == "xcm":
+        voc.set_option("xcm", 1)
     elif mode == "eager":
         voc.set_option("xcd", 0)
         voc.set_option("use_graph", 0)
@@ -71,7 +73,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
     args = ap.parse_args()
     if args.codes <= 0:
-        args.codes = 25 if args.mode == "xcd" else 1
+        args.codes = 25 if args.mode in ("xcd", "xcm") else 1
     if args.target:
         return target(args.mode, args.utterances, args.codes)
 
@@ -91,7 +93,7 @@ def main():
         if rc != 0:
             print(f"[collect_traffic] pass {name} failed with status {rc}: see {log.name}", file=sys.stderr)
             return 1
-        res.update(averages(out_dir, "ar_xcd" if args.mode == "xcd" else "ar_gru"))
+        res.update(averages(out_dir, {"xcd": "ar_xcd", "xcm": "ar_xcm"}.get(args.mode, "ar_gru")))
     kernels = sorted({k for k, _ in res})
     if not kernels:
         print("[collect_traffic] no dispatch of the decode kernel in the counter files", file=sys.stderr)
@@ -102,14 +104,15 @@ def main():
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
     alg = 4.0 * (2408448 + args.utterances * (2 * 896 + 2 * 3 * 896))
     steps = 320 * args.codes
-    if args.mode == "xcd":                # one launch per call: a copy of the recurrent weights per XCD + conditioning rows + waveform
+    one_launch = args.mode in ("xcd", "xcm")
+    if one_launch:                        # one launch per call: a copy of the recurrent weights per XCD + conditioning rows + waveform
         alg = 4.0 * (8 * (2408448 + 688128 + 229376 + 65536) + args.utterances * steps) + 4.0 * args.utterances * (steps // 160 + 1) * 2688
     elif ", 1>" in kern or ", 2>" in kern:   # fused launch: fc2 + draw of the previous sample rides along (W_fc2 once, fc1 outputs per utterance)
         alg += 4.0 * (65536 + args.utterances * 256)
-    if args.mode != "xcd" and ", 2>" in kern:                    # ... and fc1 (W_fc1 once; the state it reads is the one the GRU reads)
+    if not one_launch and ", 2>" in kern:                    # ... and fc1 (W_fc1 once; the state it reads is the one the GRU reads)
         alg += 4.0 * 229376
     out = {"kernel": kern, "utterances": args.utterances, "launch_mode": args.mode,
-           "samples_per_launch": args.utterances * steps if args.mode == "xcd" else args.utterances,
+           "samples_per_launch": args.utterances * steps if one_launch else args.utterances,
            "dispatches_averaged": res[(kern, "FETCH_SIZE")][0],
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "TCC_HIT_sum": hit, "TCC_MISS_sum": miss, "l2_hit_rate": hit / max(hit + miss, 1.0),

@@ -8,10 +8,12 @@
                                                                            -> <round>_bench_default_kernel_stats.csv, <round>_bench_default_traced.json
   pmc          tools/collect_traffic.py (per-XCD decoders, 32 utterances)  -> <round>_pmc_traffic.json
   pmc_big      tools/collect_traffic.py --utterances 128 --mode graph16    -> <round>_pmc_traffic_big128.json
+  pmc_xcm      tools/collect_traffic.py --utterances 128 --mode xcm        -> <round>_pmc_traffic_xcm128.json
   encoder      rocprofv3 --kernel-trace --stats -- python3 tools/profile_encoder.py [c1]
                                                                            -> <round>_encoder_c2_kernel_stats.csv, <round>_encoder_c1_kernel_stats.csv
-  timeline     tools/xcd_timeline.py 1 8 32 (debug build with stamps)      -> <round>_xcd_timeline.txt
-  probe        tools/xcd_decoder_probe.py                                  -> <round>_xcd_probe.csv
+  timeline     tools/xcd_timeline.py 1 8 32, tools/xcm_timeline.py 128 (debug build with stamps)
+                                                                           -> <round>_xcd_timeline.txt, <round>_xcm_timeline.txt
+  probe        tools/xcd_decoder_probe.py, tools/xcm_probe.py              -> <round>_xcd_probe.csv, <round>_xcm_probe.csv
   by_batch     tools/bench_by_batch.py                                     -> <round>_bench_by_batch.csv
   summary      rewrites the numbers quoted in profiles/<round>_summary.md from the files above
 
@@ -82,6 +84,9 @@ def main():
     if "pmc_big" not in skip:
         ok["pmc_big"] = run([PY, "tools/collect_traffic.py", "--mode", "graph16", "--utterances", "128",
                              "--out", os.path.join(P, f"{R}_pmc_traffic_big128.json")], out=os.path.join(S, "pmc_big.log"))
+    if "pmc_xcm" not in skip:
+        ok["pmc_xcm"] = run([PY, "tools/collect_traffic.py", "--mode", "xcm", "--utterances", "128",
+                             "--out", os.path.join(P, f"{R}_pmc_traffic_xcm128.json")], out=os.path.join(S, "pmc_xcm.log"))
     if "encoder" not in skip:
         for case, extra in (("c2", []), ("c1", ["c1"])):
             d = os.path.join(S, "enc_" + case)
@@ -93,13 +98,15 @@ def main():
                 shutil.copy(ks, os.path.join(P, f"{R}_encoder_{case}_kernel_stats.csv"))
             ok["encoder_" + case] = bool(good and ks)
     if "timeline" not in skip:
-        ok["timeline"] = run(["sh", "tools/build_stamps.sh"]) and run([PY, "tools/xcd_timeline.py", "1", "8", "32"],
-                                                                      out=os.path.join(P, f"{R}_xcd_timeline.txt"))
+        ok["timeline"] = (run(["sh", "tools/build_stamps.sh"]) and
+                          run([PY, "tools/xcd_timeline.py", "1", "8", "32"], out=os.path.join(P, f"{R}_xcd_timeline.txt")) and
+                          run([PY, "tools/xcm_timeline.py", "128"], out=os.path.join(P, f"{R}_xcm_timeline.txt")))
     if "probe" not in skip:
         ok["probe"] = run([PY, "tools/xcd_decoder_probe.py"], out=os.path.join(S, "probe.log"))
         src = os.path.join(ROOT, "gpurun_out", "xcd_probe.csv")
         if ok["probe"] and os.path.exists(src):
             shutil.copy(src, os.path.join(P, f"{R}_xcd_probe.csv"))
+        ok["probe_xcm"] = run([PY, "tools/xcm_probe.py"], out=os.path.join(P, f"{R}_xcm_probe.csv"))
     if "by_batch" not in skip:
         ok["by_batch"] = run([PY, "tools/bench_by_batch.py", "1", "8", "16", "32", "64", "128", "256", "512"],
                              out=os.path.join(P, f"{R}_bench_by_batch.csv"))
@@ -125,7 +132,7 @@ def summary(P, R):
                 lines.append(f"* `{k}`: {keep}")
         if "one_gpu_256" in b:
             rr = b["one_gpu_256"]["roofline"]
-            lines.append(f"* `one_gpu_256.roofline`: {rr['kernel'].split(':')[0]}, launch {rr['avg_launch_us']} us, frac {rr['frac']:.4f}")
+            lines.append(f"* `one_gpu_256.roofline`: {rr['kernel'].split(':')[0].split(' (')[0]}, launch {rr['avg_launch_us']:.1f} us, frac {rr['frac']:.4f}")
         if "cpu_baseline" in b:
             c = b["cpu_baseline"]
             lines.append(f"* `cpu_baseline`: {c['value']:.0f} samples/s on {c['cores']} threads ({c['kind']}); encoder {c['encoder_frames_per_s']:.0f} frames/s")
@@ -139,7 +146,7 @@ def summary(P, R):
             lines.append(f"    * {row['Name'][:90]}: calls {row['Calls']}, average {float(row['AverageNs']) / 1e3:.2f} us, {row['Percentage']} %")
     except (OSError, ValueError, KeyError) as e:
         lines.append(f"* kernel stats missing: {e}")
-    for name in (f"{R}_pmc_traffic.json", f"{R}_pmc_traffic_big128.json"):
+    for name in (f"{R}_pmc_traffic.json", f"{R}_pmc_traffic_big128.json", f"{R}_pmc_traffic_xcm128.json"):
         try:
             t = json.load(open(os.path.join(P, name)))
             lines.append(f"* `{name}`: {t['kernel'][:70]}, {t['utterances']} utterances: traffic {t['traffic_bytes_per_launch'] / 1e6:.2f} MB per launch, "

@@ -186,7 +186,7 @@ class Vocoder(nn.Module):
 
     def last_path(self) -> int:
         """Decode loop of the last call: 0 launch-per-step kernels, 1 the 64-workgroup persistent decoder, 2 the per-XCD
-        resident decoders (``vqcpc_vocoder_last_path``)."""
+        resident decoders, 3 their matrix-core form (``vqcpc_vocoder_last_path``)."""
         return int(_lib.load().vqcpc_vocoder_last_path(self._native()))
 
     def kernel_times(self, reps: int = 1000):
