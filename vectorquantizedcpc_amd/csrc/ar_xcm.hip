@@ -12,14 +12,15 @@
 //
 // A sample step (all 16 slots of the XCD together):
 //   all waves     cell update of the 28 owned units x 16 slots (thread = (unit, slot)) from the previous step's row sums
+//                 and the embedding rows of x_{t-1} (requested before the barrier that ended the previous step)
 //                 -> h_t published; h_t of all 32 workgroups swept into LDS                               -> barrier A
 //   all waves     112 MFMAs each: [W_hh; W_fc1] h_t partial sums of the wave's tile and K half -> LDS
-//   waves 5, 11   (tile 5 = W_hh rows 80..83 + the 8 fc1 rows; high priority, so they are through first) fc1 + ReLU ->
-//                 a_t published; slot bookkeeping, conditioning rows and Gumbel noise of step t + 1 in the shadow of
-//                 that exchange; a_t swept (each wave its K half); fc2 on the matrix pipe (A fragments from LDS);
+//   waves 0, 1    (tile 5 = W_hh rows 80..83 + the 8 fc1 rows; the oldest waves of their SIMDs: see below) fc1 + ReLU ->
+//                 a_t published; a_t swept (each wave its K half); fc2 on the matrix pipe (A fragments from LDS);
 //                 Gumbel-max candidate of the 8 owned classes per slot published; the 32 candidates per slot swept,
-//                 x_t = their first argmax; the sample goes out; the embedding rows of x_t fetched for the next cell
-//                 update                                                                                -> barrier B
+//                 x_t = their first argmax; the sample goes out
+//   wave 11       slot bookkeeping, conditioning rows and Gumbel noise of step t + 1
+//   waves 0..6    the embedding rows of x_t requested                                                    -> barrier B
 // Exchanges are the 8-byte {tag, value} granules of ar_xcd.hip, two per 16-byte load, laid out so that every sweep reads
 // a linear array.  Every wait is wall-clock bounded (status bit 0, vqcpc_vocoder_check); placement is checked as there.
 #include "ar_xcd.h"
@@ -68,7 +69,7 @@ struct Lds {
     static constexpr int aT = hT + BX * HSD;              // [BX][ASD]   a_t
     static constexpr int f2a = aT + BX * ASD;             // [16 blocks][64 lanes][4]  fc2 A fragments (8 classes + 8 zero rows)
     static constexpr int part = f2a + 16 * 64 * 4;        // [3][LROWS][BX]  q0 + q1 | q2 | q3 of every row
-    static constexpr int fcx = part + 3 * LROWS * BX;     // [2][16][BX]  fc2: q2 | q3 from wave 11
+    static constexpr int fcx = part + 3 * LROWS * BX;     // [2][16][BX]  fc2: q2 | q3 from wave 1
     static constexpr int gcl = fcx + 2 * 16 * BX;         // [BX][84]  conditioning rows in use [gate][unit]
     static constexpr int noise = gcl + BX * 84;           // [2][BX][8]
     static constexpr int mtab = noise + 2 * BX * 8;       // [NC]
@@ -76,7 +77,7 @@ struct Lds {
     static constexpr int xs = sinfo + 2 * BX * 8;         // int [BX]  x_t
     static constexpr int segst = xs + BX;                 // int [BX][8] {index, row, t0, len, utt, samples into / index of the conditioning frame}
     static constexpr int bqs = segst + BX * 8;            // [3][32] b_hh of the owned units, then b_fc1 [8], b_fc2 [8] of the owned rows
-    static constexpr int ctl = bqs + 112;                   // int [8] {xcc, rank, ok, abort, and three wave 5 <-> wave 11 flags: fc1 sums, fc2 sums, bookkeeping}
+    static constexpr int ctl = bqs + 112;                   // int [12] {xcc, rank, ok, abort, [4] fc1 halves of wave 1 in LDS, [5] its fc2 halves, [7] x_t posted (counts both fc waves)}
     static constexpr int total = ctl + 12;
 };
 
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
     }
     __syncthreads();
 
-    // ---- slot bookkeeping (lane b < 16 of wave 5 = slot b; the segment state lives in LDS): what step `tn` needs that does
+    // ---- slot bookkeeping (lane b < 16 of wave BOOK = slot b; the segment state lives in LDS): what step `tn` needs that does
     // not depend on the data: sinfo[tn & 1][slot] = {active, first, lt, utt, row, conditioning frame to load or -1}
     auto advance = [&](int tn, unsigned ln) {
         if (ln >= (unsigned)BX) return;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         int *si = sinfo + ((tn & 1) * BX + (int)ln) * 8;
         si[0] = active ? 1 : 0; si[1] = lt == 0 ? 1 : 0; si[2] = lt; si[3] = (int)sg_utt; si[4] = sg_row; si[5] = frame;
     };
-    // conditioning rows of the slots that enter a new frame at step tn, and the Gumbel noise of that step's draw (wave 5)
+    // conditioning rows of the slots that enter a new frame at step tn, and the Gumbel noise of that step's draw (wave BOOK)
     auto prepare = [&](int tn, unsigned ln) {
         const int *sn = sinfo + (tn & 1) * BX * 8;
         unsigned long long fresh = __ballot(ln < (unsigned)bx && sn[(ln & 15u) * 8 + 5] >= 0);       // slots entering a new frame (once per hop each)
