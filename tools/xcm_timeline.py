@@ -45,8 +45,9 @@ for B in [int(a) for a in sys.argv[1:]] or [128]:
         ("wave 1: MFMAs done -> its partial sums in LDS, flag set", a[:, 19] - a[:, 16]),
         ("wave 0: MFMAs done -> wave 1's halves seen", a[:, 18] - a[:, 4]),
         ("wave 0: -> a_t published (fc1 + ReLU)", a[:, 5] - a[:, 18]),
-        ("wave 0: its half of a_t swept", a[:, 6] - a[:, 5]),
-        ("wave 0: fc2 MFMAs", a[:, 20] - a[:, 6]),
+        ("wave 0: a_t of all slots swept (every wave but the bookkeeper)", a[:, 6] - a[:, 5]),
+        ("wave 0: barrier C", a[:, 7] - a[:, 6]),
+        ("wave 0: fc2 MFMAs", a[:, 20] - a[:, 7]),
         ("wave 0: -> wave 1's halves seen", a[:, 21] - a[:, 20]),
         ("wave 0: -> candidates published", a[:, 8] - a[:, 21]),
         ("wave 0: candidates swept, x_t, sample out", a[:, 9] - a[:, 8]),

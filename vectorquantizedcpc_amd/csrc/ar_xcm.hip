@@ -16,9 +16,11 @@
 //                 -> h_t published; h_t of all 32 workgroups swept into LDS                               -> barrier A
 //   all waves     112 MFMAs each: [W_hh; W_fc1] h_t partial sums of the wave's tile and K half -> LDS
 //   waves 0, 1    (tile 5 = W_hh rows 80..83 + the 8 fc1 rows; the oldest waves of their SIMDs: see below) fc1 + ReLU ->
-//                 a_t published; a_t swept (each wave its K half); fc2 on the matrix pipe (A fragments from LDS);
-//                 Gumbel-max candidate of the 8 owned classes per slot published; the 32 candidates per slot swept,
-//                 x_t = their first argmax; the sample goes out
+//                 a_t published
+//   waves 0..10   a_t of all 32 workgroups swept into LDS (three 16-byte chunks per thread)              -> barrier C
+//   waves 0, 1    fc2 on the matrix pipe (A fragments from LDS, a K half each); Gumbel-max candidate of the 8 owned classes
+//                 per slot published; the 32 candidates per slot swept, x_t = their first argmax; the sample goes out
+//                 (fc2's eight chains on eight waves + one more barrier: measured, 11.06 against 10.91 us per step)
 //   wave 11       slot bookkeeping, conditioning rows and Gumbel noise of step t + 1
 //   waves 0..6    the embedding rows of x_t requested                                                    -> barrier B
 // Exchanges are the 8-byte {tag, value} granules of ar_xcd.hip, two per 16-byte load, laid out so that every sweep reads
@@ -408,13 +410,6 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 for (int i = 0; i < 4; ++i) { pw[(LROWS + i) * BX] = qa[i]; pw[(2 * LROWS + i) * BX] = qb[i]; }
             }
         }
-        if (wave == BOOK) {
-            // ---- bookkeeping, conditioning rows and Gumbel noise of step t + 1
-            const unsigned ln = opq(lane);
-            advance(t + 1, ln);
-            lds_fence();
-            prepare(t + 1, ln);
-        }
         if (fcw) {
             // ================================================================  waves 0 and 1: everything behind fc1
             if (kh == 1) { flag_set(4, tag, opq(lane)); XM_STAMP(1, 19); }
@@ -434,32 +429,55 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                         xd_put(ga, ((unsigned)(FPB * rank + f) * BX + arow) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
                     }
                 }
+                flag_set(6, tag, ln);                                  // the other waves may start looking for a_t
                 XM_STAMP(0, 5);
             }
-            // ---- a_t: this wave's K half = rows 128 kh .. + 127 of all 16 slots: 1024 chunks, 16 per lane in two rounds
-#pragma unroll 1
-            for (int rnd = 0; rnd < 2; ++rnd) {
-                const unsigned ln = opq(lane);
-                u32x4 v[8];
-                const u64 *b0 = ga + (size_t)(128 * kh) * BX + (size_t)rnd * 1024;
+        }
+        // ---- a_t of all 16 slots (2048 16-byte chunks (row, slot pair), a linear array) swept by every wave but the bookkeeper,
+        // three chunks per thread: behind the MFMA phase every wave is idle, and two waves would need two rounds of eight
+        if (wave != BOOK) {
+            const unsigned td = opq(tid);                                          // threads 0 .. 703
+            u32x4 v[3];
+            if (wave != 0) {
+                // not before this workgroup's own rows are out (the others' are about as far): polling earlier only keeps the
+                // memory pipe busy that wave 0's stores have to get through
                 wt.start();
-                for (unsigned spins = 0;; ++spins) {
-                    chunks8(v, b0, ln * 16u);
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) ok &= v[i].y == tag && v[i].w == tag;
-                    if (__all(ok)) break;
-                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                for (unsigned spins = 0; __hip_atomic_load(s_ctl + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tag; ++spins) {
+                    if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
                 }
+            }
+            wt.start();
+            for (unsigned spins = 0;; ++spins) {
+                chunks3(v, ga, ga + 1408, ga + 2816, td * 16u);
+                bool ok = true;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const unsigned c = ln + 64u * i + 512u * rnd;
-                    const unsigned r = 128u * kh + (c >> 3), pr = c & 7u;
+                for (int i = 0; i < 3; ++i) ok &= (td + 704u * i >= (unsigned)(XM_A / 2)) || (v[i].y == tag && v[i].w == tag);
+                if (__all(ok)) break;
+                if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned c = td + 704u * i;
+                if (c < (unsigned)(XM_A / 2)) {
+                    const unsigned r = c >> 3, pr = c & 7u;
                     aT[(2 * pr) * ASD + r] = __uint_as_float(v[i].x);
                     aT[(2 * pr + 1) * ASD + r] = __uint_as_float(v[i].z);
                 }
             }
-            XM_STAMP(0, 6);
+        }
+        XM_STAMP(0, 6);
+        xm_barrier();                                                // C: a_t in LDS
+        if (*s_abort) break;
+        if (wave == BOOK) {
+            // ---- bookkeeping, conditioning rows and Gumbel noise of step t + 1, in the shadow of fc2 and the draw
+            const unsigned ln = opq(lane);
+            advance(t + 1, ln);
+            lds_fence();
+            prepare(t + 1, ln);
+        }
+        if (fcw) {
             XM_STAMP(0, 7);
             // ---- fc2 on the matrix pipe: 8 blocks of 16 columns of this wave's K half; rows 0..7 = the owned classes
             v4f fa, fb;
