@@ -39,19 +39,18 @@ for B in [int(a) for a in sys.argv[1:]] or [128]:
         ("wave 0: past barrier B -> h_t of the owned units published (cell update)", a[:, 1] - a[:, 0]),
         ("wave 0: h_t of all 32 workers swept into LDS", a[:, 2] - a[:, 1]),
         ("wave 0: barrier A", a[:, 3] - a[:, 2]),
-        ("wave 0: its 112 MFMAs (tile 5; the oldest wave of its SIMD)", a[:, 4] - a[:, 3]),
-        ("wave 1: its 112 MFMAs (tile 5; the oldest wave of its SIMD)", a[:, 16] - a[:, 3]),
-        ("wave 2: its 112 MFMAs (oldest of its SIMD)", a[:, 15] - a[:, 14]),
-        ("wave 1: MFMAs done -> its partial sums in LDS, flag set", a[:, 19] - a[:, 16]),
-        ("wave 0: MFMAs done -> wave 1's halves seen", a[:, 18] - a[:, 4]),
+        ("wave 0: 56 MFMAs of its quarter of tile 5 (the oldest wave of its SIMD)", a[:, 4] - a[:, 3]),
+        ("wave 1: 56 MFMAs of its quarter of tile 5 (the oldest wave of its SIMD)", a[:, 16] - a[:, 3]),
+        ("wave 4: 56 MFMAs of its first quarter (second wave of SIMD 0)", a[:, 15] - a[:, 3]),
+        ("wave 0: -> the other three quarters of tile 5 seen", a[:, 18] - a[:, 4]),
         ("wave 0: -> a_t published (fc1 + ReLU)", a[:, 5] - a[:, 18]),
-        ("wave 0: a_t of all slots swept (every wave but the bookkeeper)", a[:, 6] - a[:, 5]),
-        ("wave 0: barrier C", a[:, 7] - a[:, 6]),
-        ("wave 0: fc2 MFMAs", a[:, 20] - a[:, 7]),
-        ("wave 0: -> wave 1's halves seen", a[:, 21] - a[:, 20]),
+        ("wave 0: 56 MFMAs of its quarter of tile 4", a[:, 22] - a[:, 5]),
+        ("wave 0: its K quarter of a_t swept", a[:, 6] - a[:, 22]),
+        ("wave 0: fc2 MFMAs of its K quarter", a[:, 20] - a[:, 6]),
+        ("wave 0: -> the other three quarters seen", a[:, 21] - a[:, 20]),
         ("wave 0: -> candidates published", a[:, 8] - a[:, 21]),
-        ("wave 0: candidates swept, x_t, sample out", a[:, 9] - a[:, 8]),
-        ("wave 0: embedding rows requested, barrier B (waits for the other waves' MFMAs)", b[:, 0] - a[:, 9]),
+        ("wave 0: candidates of its four slots swept, x_t, sample out", a[:, 9] - a[:, 8]),
+        ("wave 0: embedding rows requested, barrier B", b[:, 0] - a[:, 9]),
         ("whole step", b[:, 0] - a[:, 0]),
     ]
     print(f"matrix-core per-XCD decoders, {B} utterance(s): {ms * 1e3 / n:.2f} us per sample step over the call; worker 5 of XCD 0, "

@@ -5,7 +5,8 @@
 // with a full copy of the weights held ON the CUs; workgroup `rank` owns hidden units 28 rank .. + 27 (84 gate rows of W_hh),
 // 8 rows of fc1 and 8 classes of fc2.  What changes is how a row meets the state: the 84 + 8 rows (+ 4 of padding) are six
 // 16-row tiles of v_mfma_f32_16x16x4_f32 against the 16 slots' h_t -- [W_hh; W_fc1] h_t is ONE product, fc1 rides along --
-// with the A fragments of a (tile, K half) pinned in the 112 VGPRs of one wave (12 waves = 6 tiles x 2 K halves), so that,
+// with the A fragments of two (tile, K quarter) pairs pinned in the 112 VGPRs of one wave (12 waves x 2 = 6 tiles x 4 K
+// quarters), so that,
 // as in ar_xcd.hip, no weight is fetched again after the prologue (the launch-per-step kernel this replaces pulls 172 KB
 // of W_hh into every workgroup at every sample step).  The arithmetic is the launch kernels': a row's dot product is the
 // same 8 fp32 fma chains (K quarter x x/z | y/w accumulator, ar_shared.h), combined ((q0 + q1) + q2) + q3.
@@ -14,15 +15,18 @@
 //   all waves     cell update of the 28 owned units x 16 slots (thread = (unit, slot)) from the previous step's row sums
 //                 and the embedding rows of x_{t-1} (requested before the barrier that ended the previous step)
 //                 -> h_t published; h_t of all 32 workgroups swept into LDS                               -> barrier A
-//   all waves     112 MFMAs each: [W_hh; W_fc1] h_t partial sums of the wave's tile and K half -> LDS
-//   waves 0, 1    (tile 5 = W_hh rows 80..83 + the 8 fc1 rows; the oldest waves of their SIMDs: see below) fc1 + ReLU ->
-//                 a_t published
-//   waves 0..10   a_t of all 32 workgroups swept into LDS (three 16-byte chunks per thread)              -> barrier C
-//   waves 0, 1    fc2 on the matrix pipe (A fragments from LDS, a K half each); Gumbel-max candidate of the 8 owned classes
-//                 per slot published; the 32 candidates per slot swept, x_t = their first argmax; the sample goes out
-//                 (fc2's eight chains on eight waves + one more barrier: measured, 11.06 against 10.91 us per step)
+//   all waves     2 x 56 MFMAs each: [W_hh; W_fc1] h_t, the K quarter sums of the wave's two (tile, quarter) pairs -> LDS
+//   waves 0..3    FIRST the four K quarters of tile 5 (W_hh rows 80..83 + the 8 fc1 rows; the oldest waves of their SIMDs: see
+//                 below) -> wave 0: fc1 + ReLU -> a_t published; then their quarter of tile 4; then, a K quarter of fc2 each:
+//                 a_t swept, fc2 on the matrix pipe (A fragments from LDS), wave 0: Gumbel-max candidate of the 8 owned
+//                 classes per slot published; the 32 candidates of four slots each swept, x_t = their first argmax; the
+//                 sample goes out
 //   wave 11       slot bookkeeping, conditioning rows and Gumbel noise of step t + 1
 //   waves 0..6    the embedding rows of x_t requested                                                    -> barrier B
+// Variants measured on the way and dropped (same bits each): K halves instead of quarters, tile 5 on waves 5 / 11 (11.3 us per
+// step) or 0 / 1 (11.3), a_t swept by all waves behind one more barrier (10.9), fc2's eight chains on eight waves behind yet
+// another (11.1); with the quarters (10.3): the other waves held back until a_t is published (10.4) or swept (11.1) -- whenever
+// they multiply, waves 0..3 crawl (the sweep of a_t: 0.6 us alone, 2.5 us next to them).
 // Exchanges are the 8-byte {tag, value} granules of ar_xcd.hip, two per 16-byte load, laid out so that every sweep reads
 // a linear array.  Every wait is wall-clock bounded (status bit 0, vqcpc_vocoder_check); placement is checked as there.
 #include "ar_xcd.h"
@@ -70,9 +74,9 @@ struct Lds {
     static constexpr int hT = 0;                          // [BX][HSD]   h_t
     static constexpr int aT = hT + BX * HSD;              // [BX][ASD]   a_t
     static constexpr int f2a = aT + BX * ASD;             // [16 blocks][64 lanes][4]  fc2 A fragments (8 classes + 8 zero rows)
-    static constexpr int part = f2a + 16 * 64 * 4;        // [3][LROWS][BX]  q0 + q1 | q2 | q3 of every row
-    static constexpr int fcx = part + 3 * LROWS * BX;     // [2][16][BX]  fc2: q2 | q3 from wave 1
-    static constexpr int gcl = fcx + 2 * 16 * BX;         // [BX][84]  conditioning rows in use [gate][unit]
+    static constexpr int part = f2a + 16 * 64 * 4;        // [4][LROWS][BX]  the K quarters q0 .. q3 of every row
+    static constexpr int fcx = part + 4 * LROWS * BX;     // [4][8][BX]  fc2: the K quarters of the 8 owned classes
+    static constexpr int gcl = fcx + 4 * 8 * BX;         // [BX][84]  conditioning rows in use [gate][unit]
     static constexpr int noise = gcl + BX * 84;           // [2][BX][8]
     static constexpr int mtab = noise + 2 * BX * 8;       // [NC]
     static constexpr int sinfo = mtab + NC;               // int [2][BX][8] {active, first, lt, utt, row, frame to load or -1}
@@ -99,6 +103,9 @@ __device__ __forceinline__ void chunks8(u32x4 (&v)[8], const u64 *b, unsigned of
                  "global_load_dwordx4 %6, %8, %10 offset:2048 sc1\n\tglobal_load_dwordx4 %7, %8, %10 offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
                  : "v"(off), "s"(b), "s"(b + 512) : "memory");
+}
+__device__ __forceinline__ void chunks1(u32x4 (&v)[1], const u64 *b, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(off), "s"(b) : "memory");
 }
 // three chunks from three uniform bases
 __device__ __forceinline__ void chunks3(u32x4 (&v)[3], const u64 *b0, const u64 *b1, const u64 *b2, unsigned off) {
@@ -183,26 +190,29 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
     u64 *gh = p.xg + CTL_WORDS / 2 + (size_t)xcc * XM_REGION;
     u64 *ga = gh + XM_H, *gc = ga + XM_A;
 
-    // ---- this wave's tile and K half; its A fragments: registers for the whole call
+    // ---- this wave's two (tile, K quarter) pairs; their A fragments (2 x 56 registers) stay for the whole call.
     // The SIMD's instruction arbiter serves its OLDEST wave first (measured: of three waves in the same MFMA loop the lowest
-    // wave id gets through at the single-wave rate, the next one after it, the youngest last: 2.5 / 4.2 / 5.4 us; and a young
-    // wave doing ordinary work next to older waves in their MFMA loop gets next to no issue slots: ~30 instructions took up
-    // to 2.7 us; s_setprio changes neither).  So tile 5 -- W_hh rows 80..83 + the 8 fc1 rows + padding, on which everything
-    // that is serial in a step hangs (fc1 -> a_t -> fc2 -> draw -> x_t) -- belongs to waves 0 and 1, the oldest of their SIMDs:
-    // they are through their MFMAs first and keep the issue priority for the serial path while the others multiply.
-    const bool fcw = wave < 2;
-    const int tl = fcw ? 5 : (wave - 2) % 5, kh = fcw ? wave : (wave - 2) / 5;
+    // wave id gets through at the single-wave rate, the youngest last: 2.5 / 4.2 / 5.4 us for 112 MFMAs; and a young wave doing
+    // ordinary work next to older waves in their MFMA loop gets next to no issue slots: ~30 instructions took up to 2.7 us;
+    // s_setprio changes neither).  Everything that is serial in a step hangs on tile 5 (W_hh rows 80..83 + the 8 fc1 rows +
+    // padding: fc1 -> a_t -> fc2 -> draw -> x_t), so its four K quarters are the FIRST work of waves 0..3 -- the oldest wave
+    // of each SIMD: 56 MFMAs instead of 112 until a_t can go out -- and those waves keep the serial path (one K quarter of fc2
+    // each); their second pair is a quarter of tile 4.  Waves 4..11 hold the two quarters of a K half of tiles 0..3.
+    const bool fcw = wave < 4;
+    const int tlA = fcw ? 5 : (wave - 4) >> 1, kwA = fcw ? wave : 2 * ((wave - 4) & 1);
+    const int tlB = fcw ? 4 : tlA, kwB = fcw ? wave : kwA + 1;
     const unsigned arow = lane & 15u, aq = lane >> 4;
     float wr[112];
-    {
-        const int lr = 16 * tl + (int)arow;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int lr = 16 * (h ? tlB : tlA) + (int)arow, kwq = h ? kwB : kwA;
         const float *Wrow = lr < 84 ? p.w_hh + (size_t)((lr / UPB) * HR + UPB * rank + lr % UPB) * HR
                           : lr < 92 ? p.w_fc1 + (size_t)(FPB * rank + lr - 84) * HR : nullptr;
 #pragma unroll
-        for (int b = 0; b < 28; ++b) {                                 // 16-column block 28 kh + b: K quarter 2 kh + b / 14, super-step b % 14
+        for (int b = 0; b < 14; ++b) {                                 // 16-column block 14 kw + b of the K quarter
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (Wrow) v = *(const float4 *)(Wrow + 16 * (28 * kh + b) + 4 * aq);
-            wr[4 * b] = v.x; wr[4 * b + 1] = v.y; wr[4 * b + 2] = v.z; wr[4 * b + 3] = v.w;
+            if (Wrow) v = *(const float4 *)(Wrow + 16 * (14 * kwq + b) + 4 * aq);
+            wr[56 * h + 4 * b] = v.x; wr[56 * h + 4 * b + 1] = v.y; wr[56 * h + 4 * b + 2] = v.z; wr[56 * h + 4 * b + 3] = v.w;
         }
     }
 
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         f2a[e] = row < FPB ? p.w_fc2[(size_t)(FPB * rank + row) * HF + 16 * blk + 4 * qq + comp] : 0.f;
     }
     for (unsigned e = tid; e < NC; e += THREADS) mtab[e] = p.mulaw_tab[e];
-    for (unsigned e = tid; e < 3 * LROWS * BX; e += THREADS) part[e] = 0.f;
+    for (unsigned e = tid; e < 4 * LROWS * BX; e += THREADS) part[e] = 0.f;
     for (unsigned e = tid; e < BX * 84; e += THREADS) gcl[e] = 0.f;
     for (unsigned e = tid; e < 2 * BX * 8; e += THREADS) sinfo[e] = 0;
     for (unsigned e = tid; e < BX; e += THREADS) xs[e] = NC / 2;
@@ -288,18 +298,6 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
     auto lds_fence = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     auto xm_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto aborted = [&]() { return __hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
-    // wave 0 <-> wave 1 hand-offs through an LDS word
-    auto flag_set = [&](int which, unsigned tag, unsigned ln) {
-        asm volatile("" ::: "memory");
-        if (ln == 0) __hip_atomic_store(s_ctl + which, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto flag_wait = [&](int which, unsigned tag, unsigned ln) {
-        wt.start();
-        for (unsigned spins = 0; __hip_atomic_load(s_ctl + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tag; ++spins)
-            if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
-        asm volatile("" ::: "memory");
-    };
-
     if (wave == BOOK) { advance(0, lane); lds_fence(); prepare(0, lane); }
     ps_barrier();
 
@@ -322,9 +320,10 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 float s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
                 if (active && !first) {
                     const float *pp = part + cu * BX + cs;
-                    s0 = (pp[0] + pp[LROWS * BX]) + pp[2 * LROWS * BX];
-                    s1 = (pp[UPB * BX] + pp[(LROWS + UPB) * BX]) + pp[(2 * LROWS + UPB) * BX];
-                    sn = (pp[2 * UPB * BX] + pp[(LROWS + 2 * UPB) * BX]) + pp[(2 * LROWS + 2 * UPB) * BX];
+                    constexpr int Q = LROWS * BX;
+                    s0 = ((pp[0] + pp[Q]) + pp[2 * Q]) + pp[3 * Q];
+                    s1 = ((pp[UPB * BX] + pp[Q + UPB * BX]) + pp[2 * Q + UPB * BX]) + pp[3 * Q + UPB * BX];
+                    sn = ((pp[2 * UPB * BX] + pp[Q + 2 * UPB * BX]) + pp[2 * Q + 2 * UPB * BX]) + pp[3 * Q + 2 * UPB * BX];
                     hold = hprev;
                 }
                 s0 += bqs[cu]; s1 += bqs[32 + cu]; sn += bqs[64 + cu];
@@ -373,151 +372,136 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         if (*s_abort) break;
         XM_STAMP(0, 3); XM_STAMP(2, 14);
 
-        // ---- [W_hh; W_fc1] h_t: 28 blocks of 16 columns, four MFMAs each (x, z -> accumulator 0; y, w -> accumulator 1 of the K quarter)
-        v4f qa, qb;                                                  // q_(2 kh), q_(2 kh + 1): D fragment, register i of lane (aq, arow) = row 4 aq + i of the tile, slot arow
-        {
+        // ---- [W_hh; W_fc1] h_t: a K quarter of a tile = 14 blocks of 16 columns, four MFMAs each (x, z -> accumulator 0; y, w ->
+        // accumulator 1); the quarter sum (D fragment: register i of lane (aq, arow) = row 4 aq + i of the tile, slot arow) -> LDS
+        auto quarter = [&](const float *wq, int tlq, int kwq) -> v4f {
             const unsigned ln = opq(lane);
-            const float4 *hb = (const float4 *)(hT + (ln & 15u) * HSD + 448 * kh + 4 * (ln >> 4));     // B fragments: h_t[slot][16 (28 kh + b) + 4 aq ..]
-            v4f acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+            const float4 *hb = (const float4 *)(hT + (ln & 15u) * HSD + 224 * kwq + 4 * (ln >> 4));     // B fragments: h_t[slot][16 (14 kw + b) + 4 aq ..]
+            v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             float4 q[3];
             q[0] = hb[0]; q[1] = hb[4];
 #pragma unroll
-            for (int b = 0; b < 28; ++b) {
-                if (b + 2 < 28) q[(b + 2) % 3] = hb[4 * (b + 2)];
+            for (int b = 0; b < 14; ++b) {
+                if (b + 2 < 14) q[(b + 2) % 3] = hb[4 * (b + 2)];
                 const float4 hv = q[b % 3];
-                const int kwl = b / 14;
-                acc[kwl][0] = XM_MFMA(wr[4 * b + 0], hv.x, acc[kwl][0]);
-                acc[kwl][1] = XM_MFMA(wr[4 * b + 1], hv.y, acc[kwl][1]);
-                acc[kwl][0] = XM_MFMA(wr[4 * b + 2], hv.z, acc[kwl][0]);
-                acc[kwl][1] = XM_MFMA(wr[4 * b + 3], hv.w, acc[kwl][1]);
+                acc0 = XM_MFMA(wq[4 * b + 0], hv.x, acc0);
+                acc1 = XM_MFMA(wq[4 * b + 1], hv.y, acc1);
+                acc0 = XM_MFMA(wq[4 * b + 2], hv.z, acc0);
+                acc1 = XM_MFMA(wq[4 * b + 3], hv.w, acc1);
             }
-            qa = acc[0][0] + acc[0][1]; qb = acc[1][0] + acc[1][1];
-        }
-        XM_STAMP(0, 4); XM_STAMP(2, 15); XM_STAMP(1, 16);
-        v4f p01 = qa + qb;                                           // meaningful in the kh = 0 waves
-#ifdef VQCPC_XD_STAMPS
-        asm volatile("" : "+v"(p01));
-        XM_STAMP(0, 22); XM_STAMP(1, 23);
-#endif
-        {
-            const unsigned ln = opq(lane);
-            float *pw = part + (16 * tl + 4 * (ln >> 4)) * BX + (ln & 15u);
-            if (kh == 0) {
+            const v4f qs = acc0 + acc1;
+            float *pw = part + ((size_t)kwq * LROWS + 16 * tlq + 4 * (ln >> 4)) * BX + (ln & 15u);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pw[i * BX] = p01[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { pw[(LROWS + i) * BX] = qa[i]; pw[(2 * LROWS + i) * BX] = qb[i]; }
-            }
-        }
+            for (int i = 0; i < 4; ++i) pw[i * BX] = qs[i];
+            return qs;
+        };
+        const v4f qA = quarter(wr, tlA, kwA);
+        XM_STAMP(0, 4); XM_STAMP(1, 16); XM_STAMP(4, 15);
         if (fcw) {
-            // ================================================================  waves 0 and 1: everything behind fc1
-            if (kh == 1) { flag_set(4, tag, opq(lane)); XM_STAMP(1, 19); }
-            else {
-                // ---- fc1 + ReLU -> a_t published: tile rows 4..11 = fc1 rows 0..7 (lanes aq = 1, 2)
+            // ================================================================  waves 0..3: tile 5 first, then everything behind fc1
+            if (wave != 0) {
+                asm volatile("" ::: "memory");
+                if (opq(lane) == 0) __hip_atomic_fetch_add(s_ctl + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // this quarter of tile 5 is in LDS
+                XM_STAMP(1, 19);
+            } else {
+                // ---- fc1 + ReLU -> a_t published: tile rows 4..11 = fc1 rows 0..7 (lanes aq = 1, 2); quarter 0 is in registers
                 const unsigned ln = opq(lane), aq = ln >> 4, arow = ln & 15u;
-                flag_wait(4, tag, ln);
+                wt.start();
+                for (unsigned spins = 0; __hip_atomic_load(s_ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 3 * (int)tag; ++spins)
+                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                asm volatile("" ::: "memory");
                 XM_STAMP(0, 18);
                 if (aq == 1 || aq == 2) {
                     const float *pr = part + (80 + 4 * aq) * BX + arow;
+                    constexpr int Q = LROWS * BX;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int f = 4 * ((int)aq - 1) + i;
-                        float v = (p01[i] + pr[(LROWS + i) * BX]) + pr[(2 * LROWS + i) * BX];
+                        float v = ((qA[i] + pr[Q + i * BX]) + pr[2 * Q + i * BX]) + pr[3 * Q + i * BX];
                         v += bqs[96 + f];
                         v = v > 0.f ? v : 0.f;
                         xd_put(ga, ((unsigned)(FPB * rank + f) * BX + arow) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
                     }
                 }
-                flag_set(6, tag, ln);                                  // the other waves may start looking for a_t
                 XM_STAMP(0, 5);
             }
         }
-        // ---- a_t of all 16 slots (2048 16-byte chunks (row, slot pair), a linear array) swept by every wave but the bookkeeper,
-        // three chunks per thread: behind the MFMA phase every wave is idle, and two waves would need two rounds of eight
-        if (wave != BOOK) {
-            const unsigned td = opq(tid);                                          // threads 0 .. 703
-            u32x4 v[3];
-            if (wave != 0) {
-                // not before this workgroup's own rows are out (the others' are about as far): polling earlier only keeps the
-                // memory pipe busy that wave 0's stores have to get through
-                wt.start();
-                for (unsigned spins = 0; __hip_atomic_load(s_ctl + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tag; ++spins) {
-                    if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-            wt.start();
-            for (unsigned spins = 0;; ++spins) {
-                chunks3(v, ga, ga + 1408, ga + 2816, td * 16u);
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) ok &= (td + 704u * i >= (unsigned)(XM_A / 2)) || (v[i].y == tag && v[i].w == tag);
-                if (__all(ok)) break;
-                if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const unsigned c = td + 704u * i;
-                if (c < (unsigned)(XM_A / 2)) {
-                    const unsigned r = c >> 3, pr = c & 7u;
-                    aT[(2 * pr) * ASD + r] = __uint_as_float(v[i].x);
-                    aT[(2 * pr + 1) * ASD + r] = __uint_as_float(v[i].z);
-                }
-            }
-        }
-        XM_STAMP(0, 6);
-        xm_barrier();                                                // C: a_t in LDS
-        if (*s_abort) break;
+        (void)quarter(wr + 56, tlB, kwB);
+        XM_STAMP(0, 22); XM_STAMP(1, 23);
         if (wave == BOOK) {
-            // ---- bookkeeping, conditioning rows and Gumbel noise of step t + 1, in the shadow of fc2 and the draw
+            // ---- bookkeeping, conditioning rows and Gumbel noise of step t + 1
             const unsigned ln = opq(lane);
             advance(t + 1, ln);
             lds_fence();
             prepare(t + 1, ln);
         }
         if (fcw) {
-            XM_STAMP(0, 7);
-            // ---- fc2 on the matrix pipe: 8 blocks of 16 columns of this wave's K half; rows 0..7 = the owned classes
-            v4f fa, fb;
+            // ---- a_t: wave kw takes the rows of fc2's K quarter kw (64 kw .. + 63) of all 16 slots: 512 chunks, 8 per lane
             {
                 const unsigned ln = opq(lane);
-                v4f a2[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-                const float4 *ab = (const float4 *)(aT + (ln & 15u) * ASD + 128 * kh + 4 * (ln >> 4));
-                const float4 *wb = (const float4 *)f2a + (8 * kh) * 64 + ln;
+                u32x4 v[8];
+                const u64 *b0 = ga + (size_t)(64 * wave) * BX;
+                wt.start();
+                for (unsigned spins = 0;; ++spins) {
+                    chunks8(v, b0, ln * 16u);
+                    bool ok = true;
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const float4 av = ab[4 * b], wv = wb[64 * b];
-                    const int kwl = b / 4;
-                    a2[kwl][0] = XM_MFMA(wv.x, av.x, a2[kwl][0]);
-                    a2[kwl][1] = XM_MFMA(wv.y, av.y, a2[kwl][1]);
-                    a2[kwl][0] = XM_MFMA(wv.z, av.z, a2[kwl][0]);
-                    a2[kwl][1] = XM_MFMA(wv.w, av.w, a2[kwl][1]);
+                    for (int i = 0; i < 8; ++i) ok &= v[i].y == tag && v[i].w == tag;
+                    if (__all(ok)) break;
+                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
                 }
-                fa = a2[0][0] + a2[0][1]; fb = a2[1][0] + a2[1][1];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned c = ln + 64u * i;
+                    const unsigned r = 64u * wave + (c >> 3), pr = c & 7u;
+                    aT[(2 * pr) * ASD + r] = __uint_as_float(v[i].x);
+                    aT[(2 * pr + 1) * ASD + r] = __uint_as_float(v[i].z);
+                }
+            }
+            XM_STAMP(0, 6);
+            XM_STAMP(0, 7);
+            // ---- fc2 on the matrix pipe: this wave's K quarter = 4 blocks of 16 columns; rows 0..7 = the owned classes
+            v4f fq;
+            {
+                const unsigned ln = opq(lane);
+                v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const float4 *ab = (const float4 *)(aT + (ln & 15u) * ASD + 64 * wave + 4 * (ln >> 4));
+                const float4 *wb = (const float4 *)f2a + (4 * wave) * 64 + ln;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 av = ab[4 * b], wv = wb[64 * b];
+                    a0 = XM_MFMA(wv.x, av.x, a0);
+                    a1 = XM_MFMA(wv.y, av.y, a1);
+                    a0 = XM_MFMA(wv.z, av.z, a0);
+                    a1 = XM_MFMA(wv.w, av.w, a1);
+                }
+                fq = a0 + a1;
             }
             XM_STAMP(0, 20);
             {
                 const unsigned ln = opq(lane), aq = ln >> 4, arow = ln & 15u;
-                if (kh == 1) {
+                if (wave != 0) {
                     if (aq < 2) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { fcx[(4 * aq + i) * BX + arow] = fa[i]; fcx[(16 + 4 * aq + i) * BX + arow] = fb[i]; }
+                        for (int i = 0; i < 4; ++i) fcx[(wave * 8 + 4 * aq + i) * BX + arow] = fq[i];
                     }
-                    flag_set(5, tag, ln);
+                    asm volatile("" ::: "memory");
+                    if (ln == 0) __hip_atomic_fetch_add(s_ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    flag_wait(5, tag, ln);
+                    wt.start();
+                    for (unsigned spins = 0; __hip_atomic_load(s_ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 3 * (int)tag; ++spins)
+                        if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                    asm volatile("" ::: "memory");
                     XM_STAMP(0, 21);
                     // ---- Gumbel-max candidate of the 8 owned classes for slot arow: lanes aq = 0 (classes 0..3), 1 (4..7)
                     float best = 0.f;
                     int kb = 0;
                     if (aq < 2) {
-                        const v4f f01 = fa + fb;
                         const float *nz = noise + ((t & 1) * BX + arow) * 8 + 4 * aq;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            float v = (f01[i] + fcx[(4 * aq + i) * BX + arow]) + fcx[(16 + 4 * aq + i) * BX + arow];
+                            const float *fp = fcx + (4 * aq + i) * BX + arow;
+                            float v = ((fq[i] + fp[8 * BX]) + fp[16 * BX]) + fp[24 * BX];
                             v += bqs[104 + 4 * aq + i];
                             const float sc = v + nz[i];
                             if (i == 0 || sc > best) { best = sc; kb = 4 * (int)aq + i; }
@@ -532,27 +516,26 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 }
             }
             XM_STAMP(0, 8);
-            // ---- x_t: the 32 candidates of a slot = 16 chunks = one DPP row; two slot groups per wave
+            // ---- x_t: the 32 candidates of a slot = 16 chunks = one DPP row; wave w takes slots 4 w .. 4 w + 3
             {
                 const unsigned ln = opq(lane);
                 const int *si = sinfo + (t & 1) * BX * 8;
-                u32x4 v[2];
-                const unsigned c0 = (kh ? 64u : 0u) + ln, c1 = c0 + 128u;           // chunk = slot * 16 + rank pair
+                u32x4 v[1];
+                const unsigned c0 = 64u * wave + ln;                              // chunk = slot * 16 + rank pair
                 wt.start();
                 for (unsigned spins = 0;; ++spins) {
-                    chunks2(v, gc, c0 * 16u, c1 * 16u);
-                    const bool ok = (v[0].y >> 8) == tag && (v[0].w >> 8) == tag && (v[1].y >> 8) == tag && (v[1].w >> 8) == tag;
+                    chunks1(v, gc, c0 * 16u);
+                    const bool ok = (v[0].y >> 8) == tag && (v[0].w >> 8) == tag;
                     if (__all(ok)) break;
                     if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
                 }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned u0 = ordered(v[h].x), u1 = ordered(v[h].z);
+                {
+                    const unsigned u0 = ordered(v[0].x), u1 = ordered(v[0].z);
                     const unsigned u = u1 > u0 ? u1 : u0;                 // classes ascend with the rank: the first maximum wins
-                    const unsigned cl = (u1 > u0 ? v[h].w : v[h].y) & 255u;
+                    const unsigned cl = (u1 > u0 ? v[0].w : v[0].y) & 255u;
                     const unsigned m = row_max(u);
                     const unsigned x = row_min(u == m ? cl : 0xFFFFu);
-                    const int b = (int)((h ? c1 : c0) >> 4);
+                    const int b = (int)(c0 >> 4);
                     if ((ln & 15u) == 0 && b < bx) {
                         xs[b] = (int)x;
                         if (si[b * 8 + 0] && rank == (b & 31)) {          // the sample goes out (network_vocoder.py:78 output)
@@ -567,14 +550,13 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 XM_STAMP(0, 9);
             }
             XM_STAMP(0, 10); XM_STAMP(1, 17);
-            __builtin_amdgcn_s_setprio(0);
         }
         // ---- the embedding rows of x_t, requested before barrier B (both fc waves have posted their slots' x_t: word 7 counts
         // them) and used by the next cell update; an utterance's first step takes class NC / 2 instead (decided behind the barrier)
         if (tid < (unsigned)CELLS) {
             const unsigned td = opq(tid), cu = td >> 4, cs = td & 15u;
             wt.start();
-            for (unsigned spins = 0; __hip_atomic_load(s_ctl + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 * (int)tag; ++spins) {
+            for (unsigned spins = 0; __hip_atomic_load(s_ctl + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 4 * (int)tag; ++spins) {
                 if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
