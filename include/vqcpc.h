@@ -228,7 +228,7 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * recurrent weights on its 32 CUs (W_hh in VGPRs, fc1 / fc2 / the sample-embedding table in LDS) and exchanges h_t, a_t and
  * the draw candidates through its own L2; no launches per sample.  Same samples as every other path.  xcd_slots: decode
  * slots it may use (default and maximum 32); more utterances than slots run back to back in them (longest first).
- * xcm (default -1 = auto: more than xcm_min (75) and fewer than xcm_max (384) utterances in flight; 0 never; 1 whenever the
+ * xcm (default -1 = auto: more than xcm_min (68) and fewer than xcm_max (512) utterances in flight; 0 never; 1 whenever the
  * dimensions are the reference's): the same resident decoders with 16 decode slots per XCD on the matrix cores
  * (ar_xcm.hip): [W_hh; W_fc1] h_t as six v_mfma_f32_16x16x4_f32 tiles per workgroup, A fragments pinned in registers.
  * xcm_slots: decode slots it may use (default and maximum 128).  Same samples as every other path; shares xcd's timeout,

@@ -1,5 +1,5 @@
 """-m gpu: the matrix-core per-XCD resident decoders (csrc/ar_xcm.hip: 16 decode slots per XCD, the default decode path
-between 76 and 383 utterances in flight).
+between 69 and 511 utterances in flight).
 
 Checked like the VALU form in test_gpu_xcd.py: (1) bit for bit against the launch-per-step kernels (`xcd` = 0), which
 test_gpu_vocoder.py checks against the oracles on their own; (2) draw by draw against the C oracle on the same history
@@ -117,18 +117,18 @@ def test_more_utterances_than_slots_and_alone_equals_in_batch():
 
 
 def test_path_by_utterances_in_flight():
-    """The default choice: VALU per-XCD decoders up to 75 utterances in flight, the matrix-core ones from 76 to 383, launches above."""
+    """The default choice: VALU per-XCD decoders up to 68 utterances in flight, the matrix-core ones from 69 to 511, launches above."""
     voc, _ = vocoder()
-    for B, want in ((32, 2), (75, 2), (76, 3), (130, 3), (400, 0)):
+    for B, want in ((32, 2), (68, 2), (69, 3), (130, 3), (400, 3), (520, 0)):
         z = synth.randint(f"xcm/pz{B}", (B, 1), 512).cuda()
         spk = torch.zeros(B, dtype=torch.long, device="cuda")
         voc.generate(z, spk, seed=1, max_steps=8)
         voc.check()
         assert voc.last_path() == want, (B, voc.last_path())
-    voc.set_option("slots", 100)                 # 400 utterances through 100 decode slots: 100 in flight
+    voc.set_option("slots", 100)                 # 600 utterances through 100 decode slots: 100 in flight
     try:
-        z = synth.randint("xcm/pz400", (400, 1), 512).cuda()
-        voc.generate(z, torch.zeros(400, dtype=torch.long, device="cuda"), seed=1, max_steps=8)
+        z = synth.randint("xcm/pz600", (600, 1), 512).cuda()
+        voc.generate(z, torch.zeros(600, dtype=torch.long, device="cuda"), seed=1, max_steps=8)
         voc.check()
         assert voc.last_path() == 3
     finally:

@@ -112,7 +112,7 @@ def main():
             shutil.copy(src, os.path.join(P, f"{R}_xcd_probe.csv"))
         ok["probe_xcm"] = run([PY, "tools/xcm_probe.py"], out=os.path.join(P, f"{R}_xcm_probe.csv"))
     if "by_batch" not in skip:
-        ok["by_batch"] = run([PY, "tools/bench_by_batch.py", "1", "8", "16", "32", "64", "128", "256", "512"],
+        ok["by_batch"] = run([PY, "tools/bench_by_batch.py", "1", "8", "16", "32", "64", "96", "128", "256", "384", "512"],
                              out=os.path.join(P, f"{R}_bench_by_batch.csv"))
     if "summary" not in skip:
         summary(P, R)

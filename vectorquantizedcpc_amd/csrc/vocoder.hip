@@ -1607,11 +1607,11 @@ struct vqcpc_vocoder {
     int xcd_timeout_ms = 250;            // bound of its in-kernel waits
     int xcd_debug_drop_step = -1;        // tests: one worker skips a candidate publish at this step -> the waits time out
     // the same decoders on the matrix cores, 16 slots per XCD (ar_xcm.hip): -1 auto (more than xcm_min and fewer than xcm_max
-    // utterances in flight), 0 never, 1 whenever the dimensions allow.  Measured (tools/xcm_probe.py, bench_by_batch): 11.3 us
-    // per step whatever the number of slots in use -> 5.7 M samples/s at 64 utterances (VALU form through 32 slots: 6.5 M),
-    // 11.2 M at 128 and 256 (launches: 8.2 / 10.8 M), against 12.5 M on the launch path with 512 utterances in flight.
+    // utterances in flight), 0 never, 1 whenever the dimensions allow.  Measured (tools/xcm_probe.py, bench_by_batch): 10.3 us
+    // per step whatever the number of slots in use -> 6.2 M samples/s at 64 utterances (VALU form through 32 slots: 6.5 M),
+    // 12.3 M at 128 and 256 (launches: 8.2 / 10.8 M), against 12.4 M on the launch path with 512 utterances in flight.
     int xcm = -1;
-    int xcm_min = 75, xcm_max = 384;
+    int xcm_min = 68, xcm_max = 512;
     int xcm_slots = 8 * XM_BX;
     DevBuf xd_x, xd_segs;                // exchange area, slot schedule
     bool last_was_xcd = false, last_was_xcm = false;
@@ -2118,7 +2118,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     v->last_was_xcd = false; v->last_was_xcm = false;
     int nz = 0;                               // utterances that produce samples
     for (int b = 0; b < B; ++b) nz += lens[Bp + b] > 0;
-    // auto: up to xcm_min (75) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
+    // auto: up to xcm_min (68) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
     // against 3.4 / 4.7 M on the launch path), from there to xcm_max the matrix-core form through its 128 slots, above that the
     // launch-per-step kernels
     const int in_flight = v->n_slots > 0 && v->n_slots < nz ? v->n_slots : nz;
