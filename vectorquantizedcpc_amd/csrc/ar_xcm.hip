@@ -26,7 +26,9 @@
 // Variants measured on the way and dropped (same bits each): K halves instead of quarters, tile 5 on waves 5 / 11 (11.3 us per
 // step) or 0 / 1 (11.3), a_t swept by all waves behind one more barrier (10.9), fc2's eight chains on eight waves behind yet
 // another (11.1); with the quarters (10.3): the other waves held back until a_t is published (10.4) or swept (11.1) -- whenever
-// they multiply, waves 0..3 crawl (the sweep of a_t: 0.6 us alone, 2.5 us next to them).
+// they multiply, waves 0..3 crawl (the sweep of a_t: 0.6 us alone, 2.5 us next to them).  hipcc sinks every B-fragment read
+// down to its four MFMAs (read, lgkmcnt(0), 4 MFMAs, ...); pinning a 3-block look-ahead with sched_barrier makes the twelve
+// waves advance evenly instead of oldest first -- and tile 5 later: 10.4 us; look-ahead depths 2..13 without it: no change.
 // Exchanges are the 8-byte {tag, value} granules of ar_xcd.hip, two per 16-byte load, laid out so that every sweep reads
 // a linear array.  Every wait is wall-clock bounded (status bit 0, vqcpc_vocoder_check); placement is checked as there.
 #include "ar_xcd.h"
