@@ -48,18 +48,37 @@ __global__ __launch_bounds__(768) void chain_kernel(const float *a, const float 
 typedef float v4f_ __attribute__((ext_vector_type(4)));
 // the same for v_mfma_f32_16x16x4_f32 (the large-batch kernels' instruction): FOUR independent accumulators per wave, as a
 // wave of those kernels has, so that the pipe -- not the dependency -- is what is measured
-template <int N>
+template <int N, int NACC, bool LDSOP>
 __global__ __launch_bounds__(768) void chain16_kernel(const float *a, const float *b, float *d, long long *cycles, int reps) {
+    __shared__ __attribute__((aligned(16))) float hs[16 * 900];
     const int l = threadIdx.x;
     float w[N], h[8];
     for (int i = 0; i < N; ++i) w[i] = a[(l * 131 + i * 7) % 4096];
     for (int i = 0; i < 8; ++i) h[i] = b[(l * 17 + i * 3) % 4096];
+    for (int i = l; i < 16 * 900; i += blockDim.x) hs[i] = b[i % 4096];
     v4f acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     __syncthreads();
+    const float4 *hb = (const float4 *)(hs + (l & 15) * 900 + 4 * ((l >> 4) & 3));
     const long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int r = 0; r < reps; ++r) {
+        if (LDSOP) {                       // as ar_xcm.hip: one 16-byte B fragment read per four MFMAs, two blocks ahead
+            float4 q[3];
+            q[0] = hb[0]; q[1] = hb[4];
 #pragma unroll
-        for (int i = 0; i < N; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h[i & 7], acc[i & 3], 0, 0, 0);
+            for (int blk = 0; blk < N / 4; ++blk) {
+                if (blk + 2 < N / 4) q[(blk + 2) % 3] = hb[4 * (blk + 2)];
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 hv = q[blk % 3];
+                acc[(4 * blk + 0) % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * blk + 0], hv.x, acc[(4 * blk + 0) % NACC], 0, 0, 0);
+                acc[(4 * blk + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * blk + 1], hv.y, acc[(4 * blk + 1) % NACC], 0, 0, 0);
+                acc[(4 * blk + 2) % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * blk + 2], hv.z, acc[(4 * blk + 2) % NACC], 0, 0, 0);
+                acc[(4 * blk + 3) % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * blk + 3], hv.w, acc[(4 * blk + 3) % NACC], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h[i & 7], acc[i % NACC], 0, 0, 0);
+        }
     }
     const long long t1 = __builtin_amdgcn_s_memrealtime();
     if ((l & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + l / 64] = t1 - t0;
@@ -177,15 +196,51 @@ int main() {
         for (int waves : {4, 8, 12}) {
             for (int which = 0; which < 2; ++which) {
                 if (which == 0) chain4_wall_kernel<112><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
-                else chain16_kernel<112><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
+                else chain16_kernel<112, 4, false><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
                 hipDeviceSynchronize();
                 hipMemcpy(hcyc.data(), cyc, grid * waves * 8, hipMemcpyDeviceToHost);
-                double s = 0; for (int i = 0; i < grid * waves; ++i) s += hcyc[i];
-                const double ns = s / (grid * waves) * 10.0 / reps / 112;            // per instruction per wave
-                printf("%s, %3d workgroup(s) x %2d waves (%d per SIMD): %.2f ns per instruction per wave = %.2f ns per instruction per SIMD = %.1f TFLOP/s on 256 CUs\n",
-                       which == 0 ? "4x4x1 (one dependent chain) " : "16x16x4 (4 accumulators)    ", grid, waves, waves / 4, ns, ns / (waves / 4),
-                       (which == 0 ? 512.0 : 2048.0) / (ns / (waves / 4)) * 1024 * 1e-3);
+                // The SIMD serves its waves strictly oldest first (see (5)): the pipe's rate is total instructions / time of the LAST
+                // wave to finish, not the mean over waves (which counts the early finishers' idle time as throughput).
+                double mx = 0; for (int i = 0; i < grid * waves; ++i) mx = hcyc[i] > mx ? hcyc[i] : mx;
+                const double ns = mx * 10.0 / reps / 112 / (waves / 4);               // per instruction per SIMD
+                printf("%s, %3d workgroup(s) x %2d waves (%d per SIMD): %.2f ns per instruction per SIMD (last wave to finish) = %.1f TFLOP/s on 256 CUs\n",
+                       which == 0 ? "4x4x1 (one dependent chain) " : "16x16x4 (4 accumulators)    ", grid, waves, waves / 4, ns,
+                       (which == 0 ? 512.0 : 2048.0) / ns * 1024 * 1e-3);
             }
         }
+    // ---- (5) what ar_xcm.hip's MFMA phase is made of, 3 waves per SIMD on the whole chip: accumulators per wave (a row's K
+    // quarter has two fma chains, a K half four) and B fragments read from LDS
+    {
+        const int grid = 256, waves = 12;
+        auto run = [&](int which, const char *name) {
+            if (which == 0) chain16_kernel<112, 4, false><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
+            if (which == 1) chain16_kernel<112, 2, false><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
+            if (which == 2) chain16_kernel<112, 4, true><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
+            if (which == 3) chain16_kernel<112, 2, true><<<grid, 64 * waves>>>(a, b, d, cyc, reps);
+            hipDeviceSynchronize();
+            hipMemcpy(hcyc.data(), cyc, grid * waves * 8, hipMemcpyDeviceToHost);
+            double sm = 0, mx = 0; for (int i = 0; i < grid * waves; ++i) { sm += hcyc[i]; if (hcyc[i] > mx) mx = hcyc[i]; }
+            printf("16x16x4, 256 workgroups x 12 waves, %s: last wave done after %.2f us per 112 instructions = %.2f ns per instruction per SIMD (mean finishing time over waves %.2f us)\n",
+                   name, mx * 10.0 / reps / 1e3, mx * 10.0 / reps / 112 / 3, sm / (grid * waves) * 10.0 / reps / 1e3);
+            if (which == 0) {                // how the time is spread: per workgroup (= CU), the slowest of its 12 waves
+                double wmin = 1e30, wmax = 0, hist[8] = {0};
+                for (int g = 0; g < grid; ++g) {
+                    double m = 0; for (int w2 = 0; w2 < waves; ++w2) m = hcyc[g * waves + w2] > m ? hcyc[g * waves + w2] : m;
+                    m = m * 10.0 / reps / 1e3;
+                    wmin = m < wmin ? m : wmin; wmax = m > wmax ? m : wmax;
+                    hist[g % 8] += m / (grid / 8);
+                }
+                printf("   slowest wave of a workgroup, us per 112: min %.2f max %.2f over the 256 workgroups; mean by workgroup id %% 8 (= XCD):", wmin, wmax);
+                for (int x = 0; x < 8; ++x) printf(" %.2f", hist[x]);
+                printf("\n   the 12 waves of workgroup 0:");
+                for (int w2 = 0; w2 < waves; ++w2) printf(" %.2f", hcyc[w2] * 10.0 / reps / 1e3);
+                printf("\n");
+            }
+        };
+        run(0, "4 accumulators, operands in registers");
+        run(1, "2 accumulators, operands in registers");
+        run(2, "4 accumulators, B fragments from LDS ");
+        run(3, "2 accumulators, B fragments from LDS ");
+    }
     return layout_ok && bad == 0 ? 0 : 1;
 }

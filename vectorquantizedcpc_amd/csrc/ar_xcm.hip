@@ -193,8 +193,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
     u64 *ga = gh + XM_H, *gc = ga + XM_A;
 
     // ---- this wave's two (tile, K quarter) pairs; their A fragments (2 x 56 registers) stay for the whole call.
-    // The SIMD's instruction arbiter serves its OLDEST wave first (measured: of three waves in the same MFMA loop the lowest
-    // wave id gets through at the single-wave rate, the youngest last: 2.5 / 4.2 / 5.4 us for 112 MFMAs; and a young wave doing
+    // The SIMD's instruction arbiter serves its OLDEST wave first (tools/microbench_mfma4x4.hip: of three waves in the same MFMA
+    // loop the lowest wave id is through its 112 MFMAs after 1.69 us, the next after 3.37, the youngest after 5.03 -- one MFMA per
+    // 15 ns per SIMD whatever the number of waves, so a step's 336 MFMAs per SIMD are 5.1 us of matrix pipe; and a young wave doing
     // ordinary work next to older waves in their MFMA loop gets next to no issue slots: ~30 instructions took up to 2.7 us;
     // s_setprio changes neither).  Everything that is serial in a step hangs on tile 5 (W_hh rows 80..83 + the 8 fc1 rows +
     // padding: fc1 -> a_t -> fc2 -> draw -> x_t), so its four K quarters are the FIRST work of waves 0..3 -- the oldest wave
