@@ -452,7 +452,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
                     const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);
                     float4 wa = wp2[0], wb = wp2[1];                     // first weights and the noise: on their way during the sweep
-                    const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8];
+                    unsigned r8o = r8;
+                    asm volatile("" : "+v"(r8o));      // opaque: the hoisted address of this read was spilled and reloaded at every step's start
+                    const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8o];
                     u64 va[4];
                     wt.start();
                     for (unsigned spins = 0;; ++spins) {
@@ -564,13 +566,15 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         auto draw_noise = [&](int tn) {
             const int lt_b = __builtin_amdgcn_readlane(st_lt, 0), lt_b2 = __builtin_amdgcn_readlane(st_lt, 32);
             const unsigned ut_b = __builtin_amdgcn_readlane(st_utt, 0), ut_b2 = __builtin_amdgcn_readlane(st_utt, 32);
-            if (lane < 16) {
-                const int which = (int)(lane >> 3), b = sv + 2 * which;
+            unsigned ln = lane;
+            asm volatile("" : "+v"(ln));           // an opaque copy: hipcc hoisted the store address out of the sample loop and spilled it
+            if (ln < 16) {
+                const int which = (int)(ln >> 3), b = sv + 2 * which;
                 if (b < bx) {
-                    const unsigned cls = FPB * rank + (lane & 7u);
+                    const unsigned cls = FPB * rank + (ln & 7u);
                     const unsigned wd = philox_word((unsigned)(which ? lt_b2 : lt_b), which ? ut_b2 : ut_b, cls >> 2,
                                                     (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
-                    noise[(tn & 1) * (BXT * 8) + b * 8 + (lane & 7u)] = gumbel_from_word(wd);
+                    noise[(tn & 1) * (BXT * 8) + b * 8 + (ln & 7u)] = gumbel_from_word(wd);
                 }
             }
         };
