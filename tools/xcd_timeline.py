@@ -55,4 +55,6 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 32]:
     print(f"per-XCD decoders, {B} utterance(s): {ms * 1e3 / n:.2f} us per sample step over the call; worker 5 of XCD 0, "
           f"mean / min / max over 116 steps, us")
     for name, d in rows:
+        if abs(d).max() > 1e4:            # a stamp this configuration does not write (one slot per XCD: wave 1 only runs fc1)
+            continue
         print(f"  {name:66s} {d.mean():6.2f} {d.min():6.2f} {d.max():6.2f}")
