@@ -698,13 +698,10 @@ constexpr size_t lds_bytes() { return sizeof(float) * (size_t)Lds<BXT>::total; }
 
 template <int BXT>
 int launch_t(const XdParams &p, hipStream_t s) {
-    static bool attr = false;
     constexpr size_t lds = lds_bytes<BXT>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void *)ar_xcd_kernel<BXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    // per launch, not once per process: the attribute belongs to the current device, and a process may hold handles on several
+    HIP_TRY(hipFuncSetAttribute((const void *)ar_xcd_kernel<BXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((ar_xcd_kernel<BXT>), dim3(8 * NW), dim3(THREADS), lds, s, p);
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;

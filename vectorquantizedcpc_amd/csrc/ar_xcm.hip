@@ -577,14 +577,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
 size_t xm_exchange_bytes() { return (size_t)CTL_WORDS * 4 + (size_t)8 * XM_REGION * sizeof(u64); }
 
 int xm_launch(const XdParams &p, hipStream_t s) {
-    static bool attr = false;
     constexpr size_t lds = sizeof(float) * (size_t)Lds::total;
     static_assert(lds <= 160 * 1024, "LDS budget");
     VQ_REQUIRE(p.n_slots >= 1 && p.n_slots <= 8 * XM_BX, "xm_launch: %d slots do not fit 8 x %d", p.n_slots, XM_BX);
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void *)ar_xcm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    // per launch, not once per process: the attribute belongs to the current device, and a process may hold handles on several
+    HIP_TRY(hipFuncSetAttribute((const void *)ar_xcm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipMemsetAsync(p.xg, 0, xm_exchange_bytes(), s));
     hipLaunchKernelGGL(ar_xcm_kernel, dim3(8 * NW), dim3(THREADS), lds, s, p);
     HIP_TRY(hipGetLastError());
