@@ -19,7 +19,7 @@ from pathlib import Path
 
 import torch
 
-from . import ConfEncoder, ConfVocoder, Encoder, Vocoder, driver, io, loudness, preprocess, synth
+from . import ConfEncoder, ConfVocoder, Encoder, Vocoder, driver, io, loudness, synth
 
 
 def _models(args, need_vocoder):
