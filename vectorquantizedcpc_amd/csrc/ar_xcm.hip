@@ -29,6 +29,9 @@
 // they multiply, waves 0..3 crawl (the sweep of a_t: 0.6 us alone, 2.5 us next to them).  hipcc sinks every B-fragment read
 // down to its four MFMAs (read, lgkmcnt(0), 4 MFMAs, ...); pinning a 3-block look-ahead with sched_barrier makes the twelve
 // waves advance evenly instead of oldest first -- and tile 5 later: 10.4 us; look-ahead depths 2..13 without it: no change.
+// The second round of the h_t sweep in flight under an "early" quarter (K quarter 0 or 1) of every wave, a barrier, then the
+// late quarters: 11.3 us (tile 5 is complete later, and the extra barrier sits in the middle of the MFMA phase); wave 0's
+// quarter of tile 4 behind x_t instead of behind the fc1 publish: 11.2 us.
 // Exchanges are the 8-byte {tag, value} granules of ar_xcd.hip, two per 16-byte load, laid out so that every sweep reads
 // a linear array.  Every wait is wall-clock bounded (status bit 0, vqcpc_vocoder_check); placement is checked as there.
 #include "ar_xcd.h"
