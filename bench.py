@@ -63,11 +63,15 @@ def log(msg):
 
 
 def kernel_source_sha():
-    """Identity of the decode kernels a PMC measurement belongs to (.git does not travel to the GPU box)."""
+    """Identity of the decode kernels a PMC measurement belongs to (.git does not travel to the GPU box): a hash of their
+    sources without `//` comments and blank lines, so that a comment edit does not orphan a measurement."""
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, rel), "r", encoding="utf-8") as f:
+            for line in f:
+                code = line.split("//", 1)[0].rstrip()          # no string literal in these files contains "//"
+                if code.strip():
+                    h.update(code.encode("utf-8") + b"\n")
     return h.hexdigest()[:16]
 
 
