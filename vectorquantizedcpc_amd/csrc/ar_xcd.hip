@@ -51,221 +51,10 @@ extern "C" int vqcpc_debug_xd_stamps(unsigned long long *out) {
 #define XD_STAMP(wv, i) do { } while (0)
 #endif
 
+#include "ar_chain.h"
+
 namespace {
 
-constexpr int HR = 896, HF = 256, NC = 256;
-constexpr int NW = 32;                 // workgroups per XCD
-constexpr int UPB = 28;                // hidden units per workgroup
-constexpr int ROWS = 3 * UPB;          // W_hh rows per workgroup
-constexpr int FPB = 8;                 // fc1 rows / fc2 classes per workgroup
-constexpr int THREADS = 768;
-constexpr int NT_H = HR / 8;           // terms of a chain over h: 112
-constexpr int NT_A = HF / 8;           // terms of a chain over a: 32
-
-// exchange area of one XCD, in granules
-__host__ __device__ constexpr int xg_h(int bxt) { return NW * bxt * 32; }         // [rank][slot][32] (28 used: two whole lines)
-__host__ __device__ constexpr int xg_a(int bxt) { return NW * bxt * FPB; }        // [rank][slot][8]
-__host__ __device__ constexpr int xg_c() { return NW * 16; }                      // [rank][16] (one line per rank)
-__host__ __device__ constexpr int xg_region(int bxt) { return xg_h(bxt) + xg_a(bxt) + xg_c(); }
-constexpr int CTL_WORDS = 64;          // u32: arrivals per XCC [0..7], total [8]
-
-
-
-// Granule traffic is addressed as (uniform 64-bit base in SGPRs) + (32-bit byte offset in a VGPR) + immediate: a 64-bit
-// address per lane and granule costs two VGPRs each, and the chain waves have none to spare.  The loads are sc1 (served by
-// L2, not by this CU's L1); each helper issues its loads together and returns when they have landed (hipcc does not count
-// the memory operations of an asm statement, so the wait is part of it; nor does it pad the hazard between a VALU write of
-// the base SGPRs (v_readfirstlane) and a vector-memory instruction inside the statement reading them: every statement
-// opens with the five wait states itself -- without them the stamped build and the 2-slot instantiation faulted).
-template <int STEP>
-__device__ __forceinline__ void gran_load1(u64 (&v)[1], const u64 *base, unsigned off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(off), "s"(base) : "memory");
-}
-template <int STEP>
-__device__ __forceinline__ void gran_load2(u64 (&v)[2], const u64 *base, unsigned off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3 sc1\n\tglobal_load_dwordx2 %1, %2, %3 offset:%4 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(off), "s"(base), "i"(STEP) : "memory");
-}
-template <int STEP>
-__device__ __forceinline__ void gran_load4(u64 (&v)[4], const u64 *base, unsigned off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5 sc1\n\tglobal_load_dwordx2 %1, %4, %5 offset:%6 sc1\n\t"
-                 "global_load_dwordx2 %2, %4, %5 offset:%7 sc1\n\tglobal_load_dwordx2 %3, %4, %5 offset:%8 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(base), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP) : "memory");
-}
-template <int STEP>     // granules at off, off + STEP (from base) and the same two from base2
-__device__ __forceinline__ void gran_load4b(u64 (&v)[4], const u64 *base, const u64 *base2, unsigned off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5 sc1\n\tglobal_load_dwordx2 %1, %4, %5 offset:%7 sc1\n\t"
-                 "global_load_dwordx2 %2, %4, %6 sc1\n\tglobal_load_dwordx2 %3, %4, %6 offset:%7 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(base), "s"(base2), "i"(STEP) : "memory");
-}
-template <int STEP>     // the same for two slots (second slot SLOT2 bytes further): eight granules in flight together
-__device__ __forceinline__ void gran_load8b(u64 (&v)[2][4], const u64 *base, const u64 *base2, unsigned off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %8, %9 sc1\n\tglobal_load_dwordx2 %1, %8, %9 offset:%11 sc1\n\t"
-                 "global_load_dwordx2 %2, %8, %10 sc1\n\tglobal_load_dwordx2 %3, %8, %10 offset:%11 sc1\n\t"
-                 "global_load_dwordx2 %4, %8, %9 offset:128 sc1\n\tglobal_load_dwordx2 %5, %8, %9 offset:%12 sc1\n\t"
-                 "global_load_dwordx2 %6, %8, %10 offset:128 sc1\n\tglobal_load_dwordx2 %7, %8, %10 offset:%12 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])
-                 : "v"(off), "s"(base), "s"(base2), "i"(STEP), "i"(STEP + 128) : "memory");
-}
-// 2 N granules: N at `off` + i STEP and N at `off2` + i STEP, all in flight together
-template <int N, int STEP>
-__device__ __forceinline__ void gran_load_pair(u64 (&a)[N], u64 (&b)[N], const u64 *base, unsigned off, unsigned off2) {
-    if constexpr (N == 1)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %4 sc1\n\tglobal_load_dwordx2 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(a[0]), "=&v"(b[0]) : "v"(off), "v"(off2), "s"(base) : "memory");
-    if constexpr (N == 2)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %6 sc1\n\tglobal_load_dwordx2 %1, %4, %6 offset:%7 sc1\n\t"
-                     "global_load_dwordx2 %2, %5, %6 sc1\n\tglobal_load_dwordx2 %3, %5, %6 offset:%7 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(b[0]), "=&v"(b[1]) : "v"(off), "v"(off2), "s"(base), "i"(STEP) : "memory");
-    if constexpr (N == 4)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %8, %10 sc1\n\tglobal_load_dwordx2 %1, %8, %10 offset:%11 sc1\n\t"
-                     "global_load_dwordx2 %2, %8, %10 offset:%12 sc1\n\tglobal_load_dwordx2 %3, %8, %10 offset:%13 sc1\n\t"
-                     "global_load_dwordx2 %4, %9, %10 sc1\n\tglobal_load_dwordx2 %5, %9, %10 offset:%11 sc1\n\t"
-                     "global_load_dwordx2 %6, %9, %10 offset:%12 sc1\n\tglobal_load_dwordx2 %7, %9, %10 offset:%13 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
-                     : "v"(off), "v"(off2), "s"(base), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP) : "memory");
-}
-template <int N, int STEP>
-__device__ __forceinline__ void gran_load(u64 (&v)[N], const u64 *base, unsigned off) {
-    if constexpr (N == 1) gran_load1<STEP>(v, base, off);
-    if constexpr (N == 2) gran_load2<STEP>(v, base, off);
-    if constexpr (N == 4) gran_load4<STEP>(v, base, off);
-}
-
-// acc += (value of `h` in lane J of this lane's quad) * w -- one fp32 fma, as the MFMA chain does it.  Eight (four)
-// consecutive terms of a chain go into ONE asm statement: hipcc pads every asm statement with an s_nop, which at one
-// fmac per statement doubled the instruction count of a chain (13 cycles per term measured; the terms of one statement
-// need no padding among themselves: the accumulator is an ordinary operand, the DPP operand comes from LDS loads).
-#define XD_QP(J) "quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
-#define XD_FMAC8(J)                                                                                                      \
-    asm("v_fmac_f32_dpp %0, %1, %9 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %2, %10 " XD_QP(J) "\n\t"                        \
-        "v_fmac_f32_dpp %0, %3, %11 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %4, %12 " XD_QP(J) "\n\t"                       \
-        "v_fmac_f32_dpp %0, %5, %13 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %6, %14 " XD_QP(J) "\n\t"                       \
-        "v_fmac_f32_dpp %0, %7, %15 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %8, %16 " XD_QP(J)                              \
-        : "+v"(acc)                                                                                                      \
-        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(h[4]), "v"(h[5]), "v"(h[6]), "v"(h[7]),                       \
-          "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]))
-#define XD_FMAC4(J)                                                                                                      \
-    asm("v_fmac_f32_dpp %0, %1, %5 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %2, %6 " XD_QP(J) "\n\t"                         \
-        "v_fmac_f32_dpp %0, %3, %7 " XD_QP(J) "\n\tv_fmac_f32_dpp %0, %4, %8 " XD_QP(J)                                \
-        : "+v"(acc)                                                                                                      \
-        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]))
-// terms 8 J .. 8 J + 7 of a 32-term phase: operands h[0..7] as held by quad lane J, weights w[0..7]
-template <int J>
-__device__ __forceinline__ void fmac8(float &acc, const float *h, const float *w) {
-    if constexpr (J == 0) XD_FMAC8(0);
-    if constexpr (J == 1) XD_FMAC8(1);
-    if constexpr (J == 2) XD_FMAC8(2);
-    if constexpr (J == 3) XD_FMAC8(3);
-}
-template <int J>
-__device__ __forceinline__ void fmac4(float &acc, const float *h, const float *w) {
-    if constexpr (J == 0) XD_FMAC4(0);
-    if constexpr (J == 1) XD_FMAC4(1);
-    if constexpr (J == 2) XD_FMAC4(2);
-    if constexpr (J == 3) XD_FMAC4(3);
-}
-// one phase: len = 32 (8 terms per quad lane) or 16 (4 per lane); w = the phase's weights in term order
-template <int LEN>
-__device__ __forceinline__ void chain_phase(float &acc, const float (&hv)[8], const float *w) {
-    if constexpr (LEN == 32) { fmac8<0>(acc, hv, w); fmac8<1>(acc, hv, w + 8); fmac8<2>(acc, hv, w + 16); fmac8<3>(acc, hv, w + 24); }
-    else { fmac4<0>(acc, hv, w); fmac4<1>(acc, hv, w + 4); fmac4<2>(acc, hv, w + 8); fmac4<3>(acc, hv, w + 12); }
-}
-
-// Lane layout of a chain wave: lane = 16 R + 4 kw + j; R = 2 rq + c0.  The quad (j = 0..3) holds chain (kw, c0) of rows
-// 4 rq + j.  Operand values of a chain sit in LDS in chain order ([cid = 2 kw + c0][n]); they are used in PHASES of 32
-// terms: in phase ph quad lane j holds terms 32 ph + 8 j .. + 7 (two 16-byte LDS words), so term n comes from quad lane
-// (n % 32) / 8, register n % 8 -- 8 operand registers per phase instead of NT / 4 for the whole chain.  A last phase of 16
-// terms (NT = 112) gives every lane 4.
-template <int NT>
-__device__ __forceinline__ float chain_regs(const float *w, const float *opnd) {
-    float acc = 0.f;
-    constexpr int NPH = (NT + 31) / 32;
-    float4 cur[2], nxt[2];
-    const float4 *op = (const float4 *)opnd;            // this lane's first word of phase 0: opnd = base + cid * NT + 8 j
-    cur[0] = op[0]; cur[1] = op[1];
-#pragma unroll
-    for (int ph = 0; ph < NPH; ++ph) {
-        constexpr int dummy = 0; (void)dummy;
-        const int len = NT - 32 * ph < 32 ? NT - 32 * ph : 32;          // 32, or 16 in the last phase of 112
-        if (ph + 1 < NPH) {
-            const int nlen = NT - 32 * (ph + 1) < 32 ? NT - 32 * (ph + 1) : 32;
-            if (nlen == 32) { nxt[0] = op[8 * (ph + 1)]; nxt[1] = op[8 * (ph + 1) + 1]; }
-            // a 16-term phase: lane j holds terms 4 j .. 4 j + 3; opnd points at word 2 j of the chain -> word 8 (ph + 1) + j is (j words back)
-            else { nxt[0] = *(const float4 *)(opnd + 32 * (ph + 1) - 4 * (int)(threadIdx.x & 3)); nxt[1] = nxt[0]; }
-        }
-        const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
-        if (len == 32) chain_phase<32>(acc, hv, w + 32 * ph);
-        else chain_phase<16>(acc, hv, w + 32 * ph);
-        cur[0] = nxt[0]; cur[1] = nxt[1];
-    }
-    return acc;
-}
-// The same chain for ONE or TWO operand vectors (two decode slots) with its weights streamed from LDS ([NT] floats at wp,
-// chain order) a phase ahead of their use: a service wave must not hold 112 weights next to everything else it keeps.
-// w0 = the weights of phase 0, already in registers (requested before the barrier the chain waits behind).
-__device__ __forceinline__ void load_phase(const float *opnd, int ph, int nlen, float4 (&d)[2]) {
-    if (nlen == 32) { d[0] = ((const float4 *)opnd)[8 * ph]; d[1] = ((const float4 *)opnd)[8 * ph + 1]; }
-    else { d[0] = *(const float4 *)(opnd + 32 * ph - 4 * (int)(threadIdx.x & 3)); d[1] = d[0]; }     // 16-term phase: lane j holds terms 4 j .. 4 j + 3
-}
-template <int NT>
-__device__ __forceinline__ void chain_lds2(const float4 *wp, const float4 (&w0)[8], const float *opA, const float *opB, bool two,
-                                           float &accA, float &accB) {
-    constexpr int NPH = (NT + 31) / 32;
-    float4 curA[2], nxtA[2], curB[2], nxtB[2], wc[8], wn[8];
-    load_phase(opA, 0, NT < 32 ? NT : 32, curA);
-    if (two) load_phase(opB, 0, NT < 32 ? NT : 32, curB);
-    else { curB[0] = curA[0]; curB[1] = curA[1]; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) wc[i] = w0[i];
-    accA = 0.f; accB = 0.f;
-#pragma unroll
-    for (int ph = 0; ph < NPH; ++ph) {
-        const int len = NT - 32 * ph < 32 ? NT - 32 * ph : 32;
-        if (ph + 1 < NPH) {
-            const int nlen = NT - 32 * (ph + 1) < 32 ? NT - 32 * (ph + 1) : 32;
-            load_phase(opA, ph + 1, nlen, nxtA);
-            if (two) load_phase(opB, ph + 1, nlen, nxtB);
-#pragma unroll
-            for (int i = 0; i < nlen / 4; ++i) wn[i] = wp[8 * (ph + 1) + i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float wv[32];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wv[4 * i] = wc[i].x; wv[4 * i + 1] = wc[i].y; wv[4 * i + 2] = wc[i].z; wv[4 * i + 3] = wc[i].w; }
-        {
-            const float hv[8] = {curA[0].x, curA[0].y, curA[0].z, curA[0].w, curA[1].x, curA[1].y, curA[1].z, curA[1].w};
-            if (len == 32) chain_phase<32>(accA, hv, wv);
-            else chain_phase<16>(accA, hv, wv);
-        }
-        if (two) {
-            const float hv[8] = {curB[0].x, curB[0].y, curB[0].z, curB[0].w, curB[1].x, curB[1].y, curB[1].z, curB[1].w};
-            if (len == 32) chain_phase<32>(accB, hv, wv);
-            else chain_phase<16>(accB, hv, wv);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        curA[0] = nxtA[0]; curA[1] = nxtA[1]; curB[0] = nxtB[0]; curB[1] = nxtB[1];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wc[i] = wn[i];
-    }
-}
-
-// Row sum from the 8 chain lanes of a row: a0 + a1 across the two 16-lane rows of an rq pair (lane ^ 16), then
-// ((q0 + q1) + q2) + q3 along the K quarters (lane + 4, + 8, + 12 inside the row) -- the order of the MFMA kernels.
-// Meaningful in lanes with kw == 0 (either c0 row).
-__device__ __forceinline__ float chain_combine(float acc) {
-    const float o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(acc), 0x401F));     // lane ^ 16
-    const float q = acc + o;
-    const float q1 = PS_DPP(q, 0x104), q2 = PS_DPP(q, 0x108), q3 = PS_DPP(q, 0x10C);               // row_shl:4 / 8 / 12
-    return ((q + q1) + q2) + q3;
-}
-
-// position of operand column k in the chain-ordered LDS copy (inverse of chain_col): [cid][n]
-__device__ __forceinline__ int chain_pos(int NS, int k) {
-    const int S = k >> 4, kw = S / NS, s = S - kw * NS;
-    const int q = (k >> 2) & 3, c0 = k & 1, ci = (k >> 1) & 1;
-    return (2 * kw + c0) * (8 * NS) + 8 * s + 4 * ci + q;
-}
 
 // LDS carve, in floats (ints behind them)
 template <int BXT> struct Lds {
@@ -304,6 +93,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         unsigned xid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
         xid &= 7u;
+        if (p.dbg_misplace && blockIdx.x == 0) xid = (xid + 1u) & 7u;      // tests: one workgroup reports the wrong XCD
         unsigned *ctl = (unsigned *)p.xg;
         const unsigned r = __hip_atomic_fetch_add(ctl + xid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         unsigned xid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
         xid &= 7u;
+        if (p.dbg_misplace && blockIdx.x == 0) xid = (xid + 1u) & 7u;      // tests: one workgroup reports the wrong XCD
         unsigned *ctl = (unsigned *)p.xg;
         const unsigned r = __hip_atomic_fetch_add(ctl + xid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
