@@ -1,5 +1,5 @@
-// Device helpers shared by the per-XCD resident decoders on the vector ALU (ar_xcd.hip: lockstep slots; ar_xcp.hip: slots
-// pipelined through the workgroup): dimensions, granule loads, and a row's fp32 fma chains on v_fmac_f32_dpp -- the same 8
+// Device helpers of the per-XCD resident decoders on the vector ALU (ar_xcd.hip; the pipelined variant of round 4, measured and
+// dropped: profiles/r04_xcp_experiment.md): dimensions, granule loads, and a row's fp32 fma chains on v_fmac_f32_dpp -- the same 8
 // chains per row as the MFMA schedule of the launch-per-step kernels (ar_shared.h), combined in the same order.
 #pragma once
 #include "ar_xcd.h"
@@ -45,12 +45,6 @@ __device__ __forceinline__ void gran_load4(u64 (&v)[4], const u64 *base, unsigne
     asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5 sc1\n\tglobal_load_dwordx2 %1, %4, %5 offset:%6 sc1\n\t"
                  "global_load_dwordx2 %2, %4, %5 offset:%7 sc1\n\tglobal_load_dwordx2 %3, %4, %5 offset:%8 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "s"(base), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP) : "memory");
-}
-// four granules at four byte offsets from one base
-__device__ __forceinline__ void gran_load4v(u64 (&v)[4], const u64 *base, unsigned o0, unsigned o1, unsigned o2, unsigned o3) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %4, %8 sc1\n\tglobal_load_dwordx2 %1, %5, %8 sc1\n\t"
-                 "global_load_dwordx2 %2, %6, %8 sc1\n\tglobal_load_dwordx2 %3, %7, %8 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base) : "memory");
 }
 template <int STEP>     // granules at off, off + STEP (from base) and the same two from base2
 __device__ __forceinline__ void gran_load4b(u64 (&v)[4], const u64 *base, const u64 *base2, unsigned off) {

@@ -5,6 +5,7 @@
 // What a decode slot does over time: utterance `row` of the call's inputs/outputs produces `len` samples starting at the
 // XCD's step t0 (its sampling-stream id is `utt`).  A slot's list ends with len == 0.
 struct XdSeg { int row, t0, len; unsigned utt; };
+static_assert(sizeof(XdSeg) == 16, "XdSeg is read as four ints");
 
 #define XD_MAX_BX 4           // decode slots per XCD the kernel is instantiated for (two service waves x two slots)
 
@@ -27,7 +28,6 @@ struct XdParams {
     int agent_stores;         // 1: publish with agent-scope (sc1) stores instead of workgroup-scope ones (tests / A-B)
     unsigned timeout_ticks;   // bound of every in-kernel wait, 100 MHz ticks
     int dbg_drop_step;        // >= 0: rank 3 of XCD 0 skips its candidate publish at that step (exercises the abort path)
-    int xp_cell_lag;          // ar_xcp.hip: chain passes between a slot's pass and its next cell update (-1: (slots per XCD - 1) / 2)
     int dbg_misplace;         // != 0: workgroup 0 reports the XCD next to its own (exercises the placement check: status 2, nothing written)
 };
 
@@ -42,11 +42,3 @@ int xd_launch(const XdParams &p, hipStream_t s);
 #define XM_BX 16
 size_t xm_exchange_bytes();
 int xm_launch(const XdParams &p, hipStream_t s);
-
-// The VALU decoders with the slots of an XCD pipelined through the workgroup instead of marching in lockstep (ar_xcp.hip):
-// every wave holds 8 rows of [W_hh; W_fc1], no workgroup barrier in the sample loop.  Same XdParams, schedule table and status
-// word; bxt = 2 or 4 slots per XCD (xp_pick_bxt).
-#define XP_MAX_BX 4
-size_t xp_exchange_bytes(int bxt);
-int xp_pick_bxt(int slots_per_xcd);            // 2, 4 (0: too many)
-int xp_launch(const XdParams &p, hipStream_t s);

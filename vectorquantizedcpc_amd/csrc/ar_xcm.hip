@@ -88,7 +88,8 @@ struct Lds {
     static constexpr int xs = sinfo + 2 * BX * 8;         // int [BX]  x_t
     static constexpr int segst = xs + BX;                 // int [BX][8] {index, row, t0, len, utt, samples into / index of the conditioning frame}
     static constexpr int bqs = segst + BX * 8;            // [3][32] b_hh of the owned units, then b_fc1 [8], b_fc2 [8] of the owned rows
-    static constexpr int ctl = bqs + 112;                   // int [12] {xcc, rank, ok, abort, [4] fc1 halves of wave 1 in LDS, [5] its fc2 halves, [7] x_t posted (counts both fc waves)}
+    static constexpr int par = bqs + 112;                   // XmPar: kernel arguments needed once per step or less, read from LDS where they are used (51 SGPRs were spilled)
+    static constexpr int ctl = par + 24;                   // int [12] {xcc, rank, ok, abort, [4] fc1 halves of wave 1 in LDS, [5] its fc2 halves, [7] x_t posted (counts both fc waves)}
     static constexpr int total = ctl + 12;
 };
 
@@ -152,12 +153,23 @@ __device__ __forceinline__ unsigned opq(unsigned x) { asm volatile("" : "+v"(x))
 
 #define XM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Kernel arguments that are needed once per sample step or less live in LDS (ints) and are read where they are used: held in
+// SGPRs for the whole call they were spilled to VGPR lanes.  (Read through the __shared__ array's own address space: a struct
+// pointer cast from it made hipcc emit FLAT loads with system scope, 0.25 us per step slower than the spills.)
+enum { PAR_WAV = 0, PAR_MULAW = 2, PAR_SEGS = 4, PAR_GCOND = 6, PAR_SEED = 8, PAR_LOUT = 10, PAR_MAXSEG, PAR_F, PAR_UPS, PAR_DROP, PAR_GEMB = 16, PAR_WORDS = 24 };
+__device__ __forceinline__ int par_i(const int *par, int i) { return __hip_atomic_load(par + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long par_q(const int *par, int i) { return (unsigned long long)(unsigned)par_i(par, i) | ((unsigned long long)(unsigned)par_i(par, i + 1) << 32); }
+// a pointer rebuilt from those words, in the GLOBAL address space (from a plain integer cast hipcc would emit flat_ loads / stores)
+#define PAR_GLOBAL(T, par, i) ((T __attribute__((address_space(1))) *)par_q(par, i))
+__device__ __forceinline__ void par_set(int *par, int i, unsigned long long v) { par[i] = (int)(unsigned)v; par[i + 1] = (int)(unsigned)(v >> 32); }
+
 __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hT = smem + Lds::hT, *aT = smem + Lds::aT, *f2a = smem + Lds::f2a, *part = smem + Lds::part, *fcx = smem + Lds::fcx;
     float *gcl = smem + Lds::gcl, *noise = smem + Lds::noise, *mtab = smem + Lds::mtab;
     int *sinfo = (int *)(smem + Lds::sinfo), *xs = (int *)(smem + Lds::xs), *s_ctl = (int *)(smem + Lds::ctl), *segst = (int *)(smem + Lds::segst);
     float *bqs = smem + Lds::bqs;
+    int *par = (int *)(smem + Lds::par);
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -182,6 +194,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
             for (int x = 0; x < 8; ++x)
                 if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
         if (!ok) __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        par_set(par, PAR_WAV, (unsigned long long)p.wav); par_set(par, PAR_MULAW, (unsigned long long)p.mulaw); par_set(par, PAR_SEGS, (unsigned long long)p.segs);
+        par_set(par, PAR_GCOND, (unsigned long long)p.Gcond); par_set(par, PAR_SEED, p.seed); par_set(par, PAR_GEMB, (unsigned long long)p.Gemb);
+        par[PAR_LOUT] = p.Lout; par[PAR_MAXSEG] = p.max_seg; par[PAR_F] = p.F; par[PAR_UPS] = p.upsample; par[PAR_DROP] = p.dbg_drop_step;
         s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = 0; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_ctl[9] = 0;
     }
     __syncthreads();
@@ -258,7 +273,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         if (sg_row >= 0 && lt >= sg_len) {                        // next utterance of this slot
             sg_i += 1;
             XdSeg sg = XdSeg{-1, 0, 0, 0u};
-            if (sg_i < p.max_seg) sg = p.segs[(size_t)(xcc + 8 * ln) * p.max_seg + sg_i];
+            const int max_seg = par_i(par, PAR_MAXSEG);
+            if (sg_i < max_seg) {
+                auto sp = PAR_GLOBAL(const int, par, PAR_SEGS) + 4 * ((size_t)(xcc + 8 * ln) * max_seg + sg_i);      // XdSeg = 4 ints
+                sg = XdSeg{sp[0], sp[1], sp[2], (unsigned)sp[3]};
+            }
             sg_row = sg.len > 0 ? sg.row : -1; sg_t0 = sg.t0; sg_len = sg.len; sg_utt = sg.utt;
             lt = tn - sg_t0;
             sg_fpos = 0; sg_fidx = 0;
@@ -267,8 +286,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         const bool active = sg_row >= 0 && lt >= 0 && lt < sg_len;
         int frame = -1;
         if (active) {
-            if (sg_fpos == p.upsample) { sg_fpos = 0; sg_fidx += 1; }
-            if (sg_fpos == 0) frame = sg_fidx < p.F ? sg_fidx : p.F - 1;      // next conditioning frame (once per hop)
+            if (sg_fpos == par_i(par, PAR_UPS)) { sg_fpos = 0; sg_fidx += 1; }
+            if (sg_fpos == 0) { const int F = par_i(par, PAR_F); frame = sg_fidx < F ? sg_fidx : F - 1; }      // next conditioning frame (once per hop)
             sg_fpos += 1;
         }
         st[5] = sg_fpos; st[6] = sg_fidx;
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
             const int f = sn[b * 8 + 5], row = sn[b * 8 + 4];
             for (unsigned e = ln; e < 84; e += 64) {
                 const unsigned g = e / UPB, u = e - g * UPB;
-                gcl[b * 84 + e] = p.Gcond[((size_t)row * p.F + f) * 3 * HR + g * HR + UPB * rank + u];
+                gcl[b * 84 + e] = PAR_GLOBAL(const float, par, PAR_GCOND)[((size_t)row * par_i(par, PAR_F) + f) * 3 * HR + g * HR + UPB * rank + u];
             }
         }
 #pragma unroll
@@ -293,7 +312,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
             const int b = (int)(ln >> 3) + 8 * h;
             if (b < bx) {
                 const unsigned cls = FPB * rank + (ln & 7u);
-                const unsigned wd = philox_word((unsigned)sn[b * 8 + 2], (unsigned)sn[b * 8 + 3], cls >> 2, (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
+                const unsigned long long seed = par_q(par, PAR_SEED);
+                const unsigned wd = philox_word((unsigned)sn[b * 8 + 2], (unsigned)sn[b * 8 + 3], cls >> 2, (unsigned)seed, (unsigned)(seed >> 32), (int)(cls & 3u));
                 noise[((tn & 1) * BX + b) * 8 + (ln & 7u)] = gumbel_from_word(wd);
             }
         }
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 const bool active = (int)cs < bx && si[0] != 0, first = si[1] != 0;
                 // the embedding rows of the sample fed in were requested before barrier B; an utterance's first step takes class NC / 2
                 if (active && first) {
-                    const float *gp = p.Gemb + (size_t)(NC / 2) * 3 * HR + UPB * rank + cu;
+                    auto gp = PAR_GLOBAL(const float, par, PAR_GEMB) + (size_t)(NC / 2) * 3 * HR + UPB * rank + cu;
                     e0 = gp[0]; e1 = gp[HR]; e2 = gp[2 * HR];
                 }
                 float s0 = 0.f, s1 = 0.f, sn = 0.f, hold = 0.f;
@@ -517,7 +537,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                     const float ob = __shfl(best, (int)ln + 16);
                     const int ok2 = __shfl(kb, (int)ln + 16);
                     if (ob > best) { best = ob; kb = ok2; }                  // lanes 0..15: first maximum over the 8 classes
-                    const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
+                    const int dstep = par_i(par, PAR_DROP);
+                    const bool drop = dstep >= 0 && t == dstep && rank == 3 && xcc == 0;
                     if (ln < (unsigned)BX && !drop)
                         xd_put(gc, (ln * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
                 }
@@ -546,9 +567,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                     if ((ln & 15u) == 0 && b < bx) {
                         xs[b] = (int)x;
                         if (si[b * 8 + 0] && rank == (b & 31)) {          // the sample goes out (network_vocoder.py:78 output)
-                            const size_t at = (size_t)si[b * 8 + 4] * p.Lout + si[b * 8 + 2];
-                            if (p.wav) p.wav[at] = mtab[x];
-                            if (p.mulaw) p.mulaw[at] = (int64_t)x;
+                            const size_t at = (size_t)si[b * 8 + 4] * par_i(par, PAR_LOUT) + si[b * 8 + 2];
+                            auto wav = PAR_GLOBAL(float, par, PAR_WAV);
+                            auto mulaw = PAR_GLOBAL(int64_t, par, PAR_MULAW);
+                            if (wav) wav[at] = mtab[x];
+                            if (mulaw) mulaw[at] = (int64_t)x;
                         }
                     }
                 }
@@ -568,7 +591,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 __builtin_amdgcn_s_sleep(2);
             }
             asm volatile("" ::: "memory");
-            const float *gp = p.Gemb + (size_t)xs[cs] * 3 * HR + UPB * rank + cu;
+            auto gp = PAR_GLOBAL(const float, par, PAR_GEMB) + (size_t)xs[cs] * 3 * HR + UPB * rank + cu;
             e0 = gp[0]; e1 = gp[HR]; e2 = gp[2 * HR];
         }
         xm_barrier();                                                // B: row sums, x_t, step t + 1's bookkeeping in LDS

@@ -1613,13 +1613,9 @@ struct vqcpc_vocoder {
     int xcm = -1;
     int xcm_min = 68, xcm_max = 512;
     int xcm_slots = 8 * XM_BX;
-    // the VALU decoders with the slots of an XCD pipelined through the workgroup (ar_xcp.hip): -1 auto (whenever the VALU form
-    // runs with two or more slots per XCD), 0 never (ar_xcd.hip's lockstep kernel), 1 as auto
-    int xcp = 0;
-    int xcp_cell_lag = -1;               // tuning: see XdParams
     int xcd_debug_misplace = 0;          // tests: workgroup 0 reports the wrong XCD -> status 2, nothing written
     DevBuf xd_x, xd_segs;                // exchange area, slot schedule
-    bool last_was_xcd = false, last_was_xcm = false, last_was_xcp = false;
+    bool last_was_xcd = false, last_was_xcm = false;
     int tf_chunk_replays = 4;            // graph replays (of steps_per_graph steps) per chunk of the teacher-forced scan
     int use_graph = 1, steps_per_graph = 160;
     int n_slots = 0;                     // 0 = one slot per utterance; else continuous batching over this many
@@ -1847,12 +1843,6 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
     }
     if (!strcmp(name, "xcd_debug_drop_step")) { v->xcd_debug_drop_step = value; return VQCPC_OK; }
     if (!strcmp(name, "xcd_debug_misplace")) { v->xcd_debug_misplace = value != 0; return VQCPC_OK; }
-    if (!strcmp(name, "xcp_cell_lag")) { v->xcp_cell_lag = value; return VQCPC_OK; }
-    if (!strcmp(name, "xcp")) {
-        VQ_REQUIRE(value >= -1 && value <= 1, "xcp must be -1 (auto), 0 or 1");
-        v->xcp = value;
-        return VQCPC_OK;
-    }
     if (!strcmp(name, "tf_chunk_replays")) {
         VQ_REQUIRE(value >= 1 && value <= 64, "tf_chunk_replays must be in [1, 64]");
         v->tf_chunk_replays = value;
@@ -1891,7 +1881,7 @@ static int persist_check(vqcpc_vocoder *v) {
 
 extern "C" int vqcpc_vocoder_last_path(vqcpc_vocoder *v) {
     if (!v) return -1;
-    return v->last_was_xcm ? 3 : v->last_was_xcp ? 4 : v->last_was_xcd ? 2 : (v->have_last ? 0 : 1);
+    return v->last_was_xcm ? 3 : v->last_was_xcd ? 2 : (v->have_last ? 0 : 1);
 }
 
 extern "C" int vqcpc_vocoder_check(vqcpc_vocoder *v) {
@@ -2127,7 +2117,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev_ptr, v->abort_host, 0));
     // One resident, weight-stationary decoder per XCD (ar_xcd.hip): utterances dealt over the XCDs' decode slots, longest
     // first onto the slot that frees up first; a slot runs its utterances back to back (no replay boundaries here).
-    v->last_was_xcd = false; v->last_was_xcm = false; v->last_was_xcp = false;
+    v->last_was_xcd = false; v->last_was_xcm = false;
     int nz = 0;                               // utterances that produce samples
     for (int b = 0; b < B; ++b) nz += lens[Bp + b] > 0;
     // auto: up to xcm_min (68) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
@@ -2142,9 +2132,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         int xs = xcm_wanted ? v->xcm_slots : (v->xcd_slots < 1 ? 1 : v->xcd_slots);
         if (v->n_slots > 0 && v->n_slots < xs) xs = v->n_slots;
         if (nz < xs) xs = nz;
-        // two or more slots per XCD on the VALU form: the pipelined kernel (ar_xcp.hip); one slot per XCD: ar_xcd.hip's
-        const bool xcp_wanted = !xcm_wanted && v->xcp != 0 && (xs + 7) / 8 >= 2;
-        const int bxt = xcm_wanted ? XM_BX : xcp_wanted ? xp_pick_bxt((xs + 7) / 8) : xd_pick_bxt((xs + 7) / 8);
+        const int bxt = xcm_wanted ? XM_BX : xd_pick_bxt((xs + 7) / 8);
         std::vector<long> xend(xs, 0);
         std::vector<std::vector<XdSeg>> lists(xs);
         for (int row : order) {
@@ -2168,7 +2156,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         }
         VQ_REQUIRE(bxt > 0 && longest < (1L << 24), "vocoder: per-XCD schedule out of range");
         TRY(v->xd_segs.reserve(tab.size() * sizeof(XdSeg)));
-        TRY(v->xd_x.reserve(xcm_wanted ? xm_exchange_bytes() : xcp_wanted ? xp_exchange_bytes(bxt) : xd_exchange_bytes(bxt)));
+        TRY(v->xd_x.reserve(xcm_wanted ? xm_exchange_bytes() : xd_exchange_bytes(bxt)));
         TRY(v->stage.upload(v->xd_segs.p, tab.data(), tab.size() * sizeof(XdSeg), s));
         xp.w_hh = v->w_hh; xp.w_fc1 = v->w_fc1; xp.b_fc1 = v->b_fc1; xp.w_fc2 = v->w_fc2; xp.b_fc2 = v->b_fc2;
         xp.Gemb = v->Gemb; xp.b_hh = v->b_hh; xp.Gcond = v->gcond.as<float>(); xp.mulaw_tab = v->mulaw_tab;
@@ -2176,14 +2164,14 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         xp.wav = wav; xp.mulaw = mulaw; xp.seed = seed; xp.max_seg = (int)max_seg; xp.n_slots = xs; xp.bxt = bxt;
         xp.Lout = Lout; xp.F = T2; xp.upsample = d.upsample_t; xp.agent_stores = v->xcd_agent_stores;
         xp.timeout_ticks = (unsigned)v->xcd_timeout_ms * 100000u; xp.dbg_drop_step = v->xcd_debug_drop_step;
-        xp.dbg_misplace = v->xcd_debug_misplace; xp.xp_cell_lag = v->xcp_cell_lag;
+        xp.dbg_misplace = v->xcd_debug_misplace;
         HIP_TRY(hipEventRecord(v->ev0, s));
-        TRY(xcm_wanted ? xm_launch(xp, s) : xcp_wanted ? xp_launch(xp, s) : xd_launch(xp, s));
+        TRY(xcm_wanted ? xm_launch(xp, s) : xd_launch(xp, s));
         HIP_TRY(hipEventRecord(v->ev1, s));
         v->last_steps = (int)longest;
         v->have_last = false;
         v->persist_pending = true;
-        v->last_was_xcd = !xcm_wanted && !xcp_wanted; v->last_was_xcm = xcm_wanted; v->last_was_xcp = xcp_wanted;
+        v->last_was_xcd = !xcm_wanted; v->last_was_xcm = xcm_wanted;
         return VQCPC_OK;
     }
     // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
