@@ -156,8 +156,9 @@ int vqcpc_encoder_context(vqcpc_encoder *enc, const float *z, int B, int Tz, flo
  * fc1 (Hf, Hr) + ReLU; fc2 (n_cls, Hf).
  * Supported: (dz + ds) % 32 == 0; Hp 64, 128 (the reference's), 256 or 512; Hr 512, 896 (the reference's) or 1024;
  * de % 32 == 0; Hf 256 (the reference's), 512, 768 or 1024; bits_mu_law 8 (the reference's), 9 or 10 with n_cls = 2^bits.
- * The resident decoders (`xcd`, `persistent`) exist for the reference's sizes (896 / 256 / 8 bits); other sizes run on the
- * launch-per-step kernels. */
+ * The resident decoders (`xcd`, `xcm`) exist for the reference's sizes (size_h_rnn 896 / size_h_fc 256 / 8-bit mu-law,
+ * config.py:69,76-77); other sizes run on the launch-per-step kernels at about half the speed -- vqcpc_vocoder_last_path says which
+ * loop a call ran. */
 typedef struct {
     const float *code_embedding;      /* (n_codes, dz)           */
     const float *speaker_embedding;   /* (n_speakers, ds)        */
@@ -213,15 +214,12 @@ int vqcpc_vocoder_glue(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *sp
 int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_t *speaker,
                             int B, int Tc, float *cond, void *stream);
 
-/* Decode-loop options.  persistent: -1 / 1 (default) = a call on ONE utterance (BASELINE configs[2]) runs on the
- * persistent decoder -- 64 workgroups resident for the whole call, all weights in registers, the three all-to-all
- * mixes of a sample step exchanged in-kernel -- when the dimensions are the reference's (size_h_rnn 896, size_h_fc 256);
- * 0 = always the launch-per-step kernels.  Both produce the same bits.  If an in-kernel exchange ever times out (1 s),
- * every workgroup leaves and the NEXT call on the handle (or vqcpc_vocoder_last_timing) returns VQCPC_ERR_HIP.
+/* Decode-loop options.
  * fuse_fc2 (default 1): in calls of up to 4 utterance tiles (64 decode slots per tile group) the fc2 + draw of sample t-1
  * and the GRU step of sample t share ONE launch -- W_hh h does not depend on the drawn sample, so it runs while the fc2
  * workgroups of the same launch produce the candidates, which the GRU's gate waves then pick up through 8-byte granules.
- * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) aborts like `persistent`.
+ * Two launches per sample instead of three; same bits.  A wait that ever times out (0.25 s) sets the handle's status word
+ * (vqcpc_vocoder_check).
  * xcd (default -1 = auto: up to xcm_min utterances in flight; 0 never, also turns xcm off; 1 whenever the dimensions are
  * the reference's): generate() runs as EIGHT resident,
  * weight-stationary decoders, one per XCD (ar_xcd.hip): decode slot s lives on XCD s % 8; each XCD keeps a full copy of the
@@ -233,8 +231,16 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * (ar_xcm.hip): [W_hh; W_fc1] h_t as six v_mfma_f32_16x16x4_f32 tiles per workgroup, A fragments pinned in registers.
  * xcm_slots: decode slots it may use (default and maximum 128).  Same samples as every other path; shares xcd's timeout,
  * debug-drop and agent-store options and its status word.
+ * The resident decoders (xcd, xcm) assume the GPU is theirs for the call: ONE launch of 256 workgroups (768 threads, ~150 KB of
+ * LDS each: one per CU) that must all be resident, 32 on each XCD, within xcd_timeout_ms -- checked in-kernel, not assumed.
+ * On a GPU shared with another process or stream the placement can miss: the launch then writes nothing and reports it
+ * (vqcpc_vocoder_check: "not dealt 32"), the handle keeps its options and the caller repeats the call; only a second miss in a
+ * row switches the resident decoders off for the handle.  A hand-off TIMEOUT inside a launch switches them off at once; the
+ * handle re-arms itself after 16 clean calls, or when xcd / fuse_fc2 is set again.
  * xcd_agent_stores / xcd_timeout_ms / xcd_debug_drop_step, handoff_timeout_ms / handoff_debug_drop_step: A-B and tests
  * of the abort path (one worker skips a publish at that step; the waits give up after the timeout; vqcpc_vocoder_check).
+ * xcd_debug_misplace (one shot): workgroup 0 of the next resident launch reports the XCD next to its own, so that the placement
+ * check fails (tests of the "not dealt 32" path).
  * tf_chunk_replays: graph replays per chunk of the teacher-forced scan (vqcpc_vocoder_logits; default 4).
  * use_graph: replay the per-sample kernels from a captured hipGraph
  * (default 1) instead of launching them one by one.  steps_per_graph: samples per replay (even).
@@ -244,19 +250,40 @@ int vqcpc_vocoder_condition(vqcpc_vocoder *voc, const int64_t *idx, const int64_
  * tiles, or of >= 2*big_min_tiles tiles, as two independent tile groups on two streams (default 1). */
 int vqcpc_vocoder_set_option(vqcpc_vocoder *voc, const char *name, int value);
 
-/* After the caller has synchronised the stream that carried vqcpc_vocoder_generate: did an in-kernel hand-off of that
- * call (per-XCD decoders, persistent decoder, fused fc2 || GRU launch) time out, or were the per-XCD decoder's workgroups
- * not dealt 32 to each XCD?  VQCPC_OK, or VQCPC_ERR_HIP: the waveform of that call is incomplete (or was not written at
- * all), the handle has fallen back to one launch per kernel and step, and the call should be repeated -- the repeat
- * gives the same samples the fast path would have (the sampling stream does not depend on the path).  Reads a
- * host-mapped word: no HIP call.  convert.py:75-83 writes the wav right after generate(): driver.convert_utterances,
- * cli.convert and shard.convert_sharded call this before anything is written or gathered. */
+/* After the caller has synchronised the stream that carried vqcpc_vocoder_generate: did an in-kernel hand-off of a call
+ * since the last check (per-XCD decoders, fused fc2 || GRU launch) time out, or were the per-XCD decoders' workgroups not
+ * dealt 32 to each XCD?  VQCPC_OK, or VQCPC_ERR_HIP: the waveform of that call is incomplete (or was not written at all) and
+ * the call should be repeated -- the repeat gives the same samples the fast path would have (the sampling stream does not
+ * depend on the path); the message names the call (the resident decoders tag the status word with the handle's call count)
+ * and says whether the handle has switched its in-kernel hand-offs off (see the options).  Reads a host-mapped word: no HIP
+ * call.  Without the synchronisation the word of a call still running reads zero: the next vqcpc_vocoder_generate on the
+ * handle looks at it again (and reports what it finds) but clears nothing.  convert.py:75-83 writes the wav right after
+ * generate(): the Python Vocoder.generate checks (and repeats once) by default; driver.convert_utterances, cli.convert and
+ * shard.convert_sharded go through it before anything is written or gathered. */
 int vqcpc_vocoder_check(vqcpc_vocoder *voc);
 
 /* Which decode loop the last generate()/logits() call on the handle ran (measurement and tests; the samples do not depend
- * on it): 0 = launch-per-step kernels, 1 = the 64-workgroup persistent single-utterance decoder, 2 = the per-XCD resident
- * decoders, 3 = their matrix-core form (16 slots per XCD); -1 = null handle. */
+ * on it): 0 = launch-per-step kernels (more than 511 utterances in flight, dimensions other than the reference's 896 / 256 /
+ * 8 bits, teacher-forced calls, the fallback), 2 = the per-XCD resident decoders, 3 = their matrix-core form (16 slots per XCD);
+ * 1 = no decode loop has run yet; -1 = null handle. */
 int vqcpc_vocoder_last_path(vqcpc_vocoder *voc);
+
+/* Which decode loop a call of B utterances producing n_samples[b] samples each would take under these options (the arguments
+ * mirror vqcpc_vocoder_set_option: xcd, xcm -1 / 0 / 1; xcm_min, xcm_max, xcd_slots, xcm_slots <= 0 = the defaults 68, 512, 32,
+ * 128; slots 0 = one per utterance), for the reference's dimensions: *path as vqcpc_vocoder_last_path, *slots_used, and *longest =
+ * the longest back-to-back schedule of a resident decode slot in samples.  Pure host arithmetic (no GPU): the rule
+ * vqcpc_vocoder_generate applies.  A slot's schedule must stay below 2^24 - 1 samples for the resident decoders; in auto mode
+ * such a call takes the launch path, with xcd / xcm = 1 it is VQCPC_ERR_INVALID. */
+int vqcpc_vocoder_plan(int xcd, int xcm, int xcm_min, int xcm_max, int xcd_slots, int xcm_slots, int slots,
+                       const int *n_samples, int B, int *path, int *slots_used, int64_t *longest);
+
+/* Decode slots the last call's loop ran through (per-XCD decoders: at most 32; matrix-core form: at most 128; launch path:
+ * the `slots` option or one per utterance); -1 = null handle. */
+int vqcpc_vocoder_last_slots(vqcpc_vocoder *voc);
+
+/* Device memory the handle's grow-only work buffers hold at the moment (conditioning rows, schedules, exchange areas, ...:
+ * the peak of the calls so far; the weights are not counted). */
+int vqcpc_vocoder_workspace_bytes(vqcpc_vocoder *voc, uint64_t *bytes);
 
 /* Device time, in milliseconds, of the whole decode loop of the last generate()/logits() call
  * (HIP events on the launch stream) and the number of samples per utterance it covers.

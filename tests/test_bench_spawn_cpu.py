@@ -46,3 +46,20 @@ def test_world_size_mismatch_is_a_clear_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
                        timeout=120, env=env, cwd=ROOT)
     assert p.returncode == 2 and "WORLD_SIZE=2" in p.stderr and "Traceback" not in p.stderr
+
+
+def test_configs4_manifest_leg_on_two_gloo_ranks():
+    """`bench.py --workload manifest` (BASELINE configs[4]: the ragged manifest LPT-sharded, decoded locally, gathered on rank 0)
+    rehearsed on CPU: two gloo ranks through the same leg (manifest_sharded -> shard.convert_sharded -> shard.gather_waveforms)
+    with a stand-in decode.  One JSON line; every utterance comes back with its own length; per-rank statistics are reported."""
+    p = _run("--gpus", "2", "--selftest-spawn", "3", "--workload", "manifest", "--manifest", "37", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["backend"] == "gloo" and r["scaling"] == "strong"
+    assert r["all_utterances_gathered_with_their_lengths"] is True
+    assert sum(r["per_rank"]["utterances"]) == 37 and min(r["per_rank"]["utterances"]) >= 1
+    assert abs(r["per_rank"]["samples"][0] - r["per_rank"]["samples"][1]) <= 0.15 * max(r["per_rank"]["samples"])      # LPT balance
+    assert r["value"] > 0 and r["steps"] == 2 and len(r["per_rank"]["gather_ms_last_step"]) == 2
+    assert "configs[4]" in r["config"]["workload"]

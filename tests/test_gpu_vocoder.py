@@ -29,7 +29,7 @@ def vocoder():
         v = V.Vocoder(V.ConfVocoder())
         v.load_state_dict(sd)
         v = v.to("cuda").eval()
-        v.set_option("xcd", 0)          # this file exercises the launch-per-step kernels and the 64-workgroup persistent decoder;
+        v.set_option("xcd", 0)          # this file exercises the launch-per-step kernels;
         _cache["v"] = (v, sd)           # the per-XCD resident decoders (the default up to 64 utterances) are in test_gpu_xcd.py
     return _cache["v"]
 
@@ -387,31 +387,29 @@ def test_teacher_forced_scan_chunks_and_training_shape():
     assert d.shape == (B2, 200, 256) and torch.equal(d[:B], a[:, :200])
 
 
-def test_persistent_single_utterance_decoder():
-    """BASELINE configs[2]: one utterance runs on the persistent decoder (weights resident in registers, in-kernel
-    granule exchanges).  It must produce the bits of the launch-per-step kernels (same fmaf chains), so an utterance
-    alone still equals itself inside a batch; and it is checked against the oracle directly, draw by draw."""
+def test_single_utterance_default_path_equals_the_launch_path():
+    """BASELINE configs[2]: one utterance runs on the per-XCD resident decoders by default (this file's fixture turns them off:
+    here they are on).  It must produce the bits of the launch-per-step kernels (same fma chains), so an utterance alone still
+    equals itself inside a batch; and it is checked against the oracle directly, draw by draw."""
     voc, sd = vocoder()
     z = synth.randint("ps/z", (1, 4), 512)
     spk = torch.tensor([7])
     try:
-        voc.set_option("persistent", 0)
         w0, m0 = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=3, return_mulaw=True)
-        t0 = voc.last_timing()
-        voc.set_option("persistent", 1)
+        assert voc.last_path() == 0
+        voc.set_option("xcd", -1)
         w1, m1 = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=3, return_mulaw=True)
-        t1 = voc.last_timing()
+        assert voc.last_path() == 2
         w2, m2 = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=3, return_mulaw=True, max_steps=333)
+        assert m0.shape == (1, 1280) and int((m0 != 0).sum()) > 1000
+        assert torch.equal(m0, m1) and torch.equal(w0, w1)
+        assert torch.equal(m2[0, :333], m0[0, :333]) and not m2[0, 333:].any() and not w2[0, 333:].any()
+        stats = _check_free_run(voc, sd, z, spk, None, seed=13, utt_base=3, steps=600)
+        assert stats[0][1] >= 0.999 * stats[0][0]
+        with pytest.raises(RuntimeError):
+            voc.kernel_times(10)               # no launch-per-step state after a resident call
     finally:
-        voc.set_option("persistent", -1)
-    print("us per sample: launch-per-step %.2f, persistent %.2f" % (t0[0] * 1e3 / t0[1], t1[0] * 1e3 / t1[1]))
-    assert m0.shape == (1, 1280) and int((m0 != 0).sum()) > 1000
-    assert torch.equal(m0, m1) and torch.equal(w0, w1)
-    assert torch.equal(m2[0, :333], m0[0, :333]) and not m2[0, 333:].any() and not w2[0, 333:].any()
-    stats = _check_free_run(voc, sd, z, spk, None, seed=13, utt_base=3, steps=600)      # default options: persistent
-    assert stats[0][1] >= 0.999 * stats[0][0]
-    with pytest.raises(RuntimeError):
-        voc.kernel_times(10)               # no launch-per-step state after a persistent call
+        voc.set_option("xcd", 0)
 
 
 def test_fused_fc2_gru_launch_same_bits_and_direct_oracle():

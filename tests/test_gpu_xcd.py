@@ -153,7 +153,6 @@ def _reference_bits(z, spk, **kw):
     ref, _ = vocoder(fresh=True)
     ref.set_option("xcd", 0)
     ref.set_option("fuse_fc2", 0)
-    ref.set_option("persistent", 0)
     wav, mu = ref.generate(z, spk, return_mulaw=True, **kw)
     ref.check()
     return wav.cpu(), mu.cpu()
@@ -169,23 +168,27 @@ def test_xcd_handoff_timeout_is_reported_by_the_same_call_and_the_rerun_is_right
     voc.set_option("xcd", 1)
     voc.set_option("xcd_timeout_ms", 20)
     voc.set_option("xcd_debug_drop_step", 200)
-    wav, mu = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True)
-    with pytest.raises(RuntimeError, match="timed out"):
+    wav, mu = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True, async_=True)      # only enqueued: the caller checks
+    with pytest.raises(RuntimeError, match=r"timed out.*call #1 of this handle|call #1 of this handle.*timed out"):
         voc.check()
     assert not bool((mu[0, 260:] != 0).any())            # the call that suffered it is incomplete (and said so)
     voc.set_option("xcd_debug_drop_step", -1)
     wav2, mu2 = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True)      # the handle has fallen back
-    voc.check()
+    assert voc.last_path() == 0
     want = _reference_bits(z, spk, seed=9, utt_base=0)
     assert torch.equal(mu2.cpu(), want[1]) and torch.equal(wav2.cpu(), want[0])
-    # the driver does the check-and-repeat itself
+    # Vocoder.generate itself (the reference's call, convert.py:77) checks and repeats once: the drop-in caller gets the right bits
     voc3, _ = vocoder(fresh=True)
     voc3.set_option("xcd", 1)
     voc3.set_option("xcd_timeout_ms", 20)
     voc3.set_option("xcd_debug_drop_step", 100)
-    with pytest.warns(UserWarning, match="repeated on the fallback path"):
-        wav3 = driver.generate_checked(voc3, z, spk, seed=9, utt_base=0)
+    with pytest.warns(UserWarning, match="decode repeated"):
+        wav3 = voc3.generate(z, spk, seed=9, utt_base=0)
     assert torch.equal(wav3.cpu(), want[0])
+    with pytest.warns(UserWarning, match="decode repeated"):
+        voc3.set_option("xcd", 1)
+        wav4 = driver.generate_checked(voc3, z, spk, seed=9, utt_base=0)
+    assert torch.equal(wav4.cpu(), want[0])
 
 
 def test_fused_launch_handoff_timeout_is_reported_and_the_rerun_is_right():
@@ -196,7 +199,7 @@ def test_fused_launch_handoff_timeout_is_reported_and_the_rerun_is_right():
     voc.set_option("xcd", 0)
     voc.set_option("handoff_timeout_ms", 20)
     voc.set_option("handoff_debug_drop_step", 150)
-    voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True)
+    voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True, async_=True)
     with pytest.raises(RuntimeError, match="timed out"):
         voc.check()
     voc.set_option("handoff_debug_drop_step", -1)
@@ -225,3 +228,123 @@ def test_resident_context_scan_timeout_is_reported_and_the_rerun_is_right():
     c2 = enc.encode(mel)[1]
     enc.check()
     assert torch.equal(c2.cpu(), want)
+
+
+# ------------------------------------------------------------------ placement misses, re-arming, pipelined callers
+
+
+@pytest.mark.parametrize("B", [4, 80])
+def test_placement_miss_writes_nothing_is_reported_and_is_not_latched(B):
+    """A shared GPU's first call: the 256 workgroups are not dealt 32 per XCD (here: workgroup 0 reports the wrong XCC_ID).
+    The launch gives up before it touches any output (status 2), check() says so for THAT call, the handle keeps its
+    options, and the repeat runs on the resident decoders again and gives the reference bits."""
+    voc, _ = vocoder(fresh=True)
+    z = synth.randint("xcd/pz", (B, 2), 512).cuda()
+    spk = synth.randint("xcd/ps", (B,), 102).cuda()
+    want_path = 2 if B <= 68 else 3
+    voc.set_option("xcd_timeout_ms", 50)
+    voc.set_option("xcd_debug_misplace", 1)
+    wav, mu = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True, async_=True)
+    with pytest.raises(RuntimeError, match="not dealt 32"):
+        voc.check()
+    assert not bool(mu.any()) and not bool(wav.any())                 # nothing was written
+    wav2, mu2 = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True)     # the misplacement was one shot; nothing latched
+    assert voc.last_path() == want_path
+    want = _reference_bits(z, spk, seed=9, utt_base=0)
+    assert torch.equal(mu2.cpu(), want[1]) and torch.equal(wav2.cpu(), want[0])
+    # the default call repeats on its own
+    voc.set_option("xcd_debug_misplace", 1)
+    with pytest.warns(UserWarning, match="not dealt 32"):
+        wav3 = voc.generate(z, spk, seed=9, utt_base=0)
+    assert voc.last_path() == want_path and torch.equal(wav3.cpu(), want[0])
+    # two misses in a row: the handle gives the resident decoders up (and says so)
+    voc.set_option("xcd_debug_misplace", 1)
+    voc.generate(z, spk, seed=9, utt_base=0, async_=True)
+    with pytest.raises(RuntimeError, match="not dealt 32"):
+        voc.check()
+    voc.set_option("xcd_debug_misplace", 1)
+    voc.generate(z, spk, seed=9, utt_base=0, async_=True)
+    with pytest.raises(RuntimeError, match="twice in a row"):
+        voc.check()
+    wav5 = voc.generate(z, spk, seed=9, utt_base=0)
+    assert voc.last_path() == 0 and torch.equal(wav5.cpu(), want[0])
+
+
+def test_a_timeout_latches_and_the_handle_rearms_after_clean_calls():
+    voc, _ = vocoder(fresh=True)
+    z = synth.randint("xcd/rz", (4, 1), 512).cuda()
+    spk = synth.randint("xcd/rs", (4,), 102).cuda()
+    voc.set_option("xcd_timeout_ms", 20)
+    voc.set_option("xcd_debug_drop_step", 50)
+    voc.generate(z, spk, seed=9, utt_base=0, async_=True)
+    with pytest.raises(RuntimeError, match="re-arms after 16 clean calls"):
+        voc.check()
+    voc.set_option("xcd_debug_drop_step", -1)
+    want = None
+    for i in range(16):
+        wav = voc.generate(z, spk, seed=9, utt_base=0)
+        assert voc.last_path() == 0, i
+        want = wav if want is None else want
+        assert torch.equal(wav, want)
+    wav = voc.generate(z, spk, seed=9, utt_base=0)                # the 17th call: resident decoders again, same bits
+    assert voc.last_path() == 2 and torch.equal(wav, want)
+
+
+def test_pipelined_calls_the_status_word_names_the_call():
+    """Three calls enqueued without a synchronisation, the second one loses a publish: the check behind the sync names call #2;
+    the third call (which saw a clean word when it was enqueued) is not blamed."""
+    voc, _ = vocoder(fresh=True)
+    z = synth.randint("xcd/qz", (4, 1), 512).cuda()
+    spk = synth.randint("xcd/qs", (4,), 102).cuda()
+    voc.set_option("xcd_timeout_ms", 20)
+    voc.generate(z, spk, seed=9, utt_base=0, async_=True)
+    voc.set_option("xcd_debug_drop_step", 50)
+    voc.generate(z, spk, seed=9, utt_base=0, async_=True)
+    voc.set_option("xcd_debug_drop_step", -1)
+    try:
+        voc.generate(z, spk, seed=9, utt_base=0, async_=True)     # may already see the word (then it raises for call #2 itself)
+    except RuntimeError as e:
+        assert "call #2 of this handle" in str(e)
+    else:
+        with pytest.raises(RuntimeError, match="call #2 of this handle"):
+            voc.check()
+
+
+# ------------------------------------------------------------------ full-size equalities and long oracle runs (VERDICT r3 item 8)
+
+
+def test_32_x_32000_bit_equal_to_the_launch_path():
+    """BASELINE configs[3]'s per-GPU shard at full size: the per-XCD decoders and the launch-per-step kernels give the same
+    1 024 000 samples (one run each)."""
+    voc, _ = vocoder()
+    z = synth.randint("xcd/fz32", (32, 100), 512).cuda()
+    spk = (torch.arange(32, device="cuda") % 102)
+    out = _both_paths(voc, z, spk, seed=13, utt_base=0)
+    assert out[1][1].shape == (32, 32000)
+    assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][0], out[0][0])
+
+
+def test_2400_consecutive_steps_draw_by_draw_against_the_oracle():
+    """A late-step divergence (tag wrap, conditioning-frame index, slot hand-over) cannot hide behind 400-step windows: 2 400
+    consecutive steps (15 conditioning frames) of two utterances inside a batch of 9 on the per-XCD decoders, every draw
+    checked against the C oracle on the same history."""
+    voc, sd = vocoder()
+    voc.set_option("xcd", 1)
+    try:
+        B, Tc, steps = 9, 8, 2400
+        z = synth.randint("xcd/lz", (B, Tc), 512)
+        spk = synth.randint("xcd/ls", (B,), 102)
+        wav, mu = voc.generate(z.cuda(), spk.cuda(), seed=21, utt_base=5, return_mulaw=True, max_steps=steps)
+        assert voc.last_path() == 2
+        mu = mu.cpu().numpy()
+        for b in (0, 8):
+            inputs = np.concatenate([[128], mu[b, :steps - 1]])
+            r = oracle.vocoder_generate(sd, z[b].numpy(), int(spk[b]), seed=21, utterance=5 + b, n_steps=steps, inputs=inputs,
+                                        want_logits=True)
+            diff = np.nonzero(r["samples"] != mu[b, :steps])[0]
+            assert len(diff) <= 0.001 * steps, (b, len(diff))
+            for t in diff:
+                pick, sc = oracle.sample_from_logits(r["logits"][t], 21, 5 + b, int(t))
+                assert sc[pick] - sc[int(mu[b, t])] <= 2e-5, (b, int(t))
+    finally:
+        voc.set_option("xcd", -1)

@@ -159,7 +159,6 @@ def _reference_bits(z, spk, **kw):
     ref, _ = vocoder(fresh=True)
     ref.set_option("xcd", 0)
     ref.set_option("fuse_fc2", 0)
-    ref.set_option("persistent", 0)
     wav, mu = ref.generate(z, spk, return_mulaw=True, **kw)
     ref.check()
     return wav.cpu(), mu.cpu()
@@ -175,7 +174,7 @@ def test_handoff_timeout_is_reported_by_the_same_call_and_the_rerun_is_right():
     voc.set_option("xcm", 1)
     voc.set_option("xcd_timeout_ms", 20)
     voc.set_option("xcd_debug_drop_step", 200)
-    wav, mu = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True)
+    wav, mu = voc.generate(z, spk, seed=9, utt_base=0, return_mulaw=True, async_=True)
     with pytest.raises(RuntimeError, match="timed out"):
         voc.check()
     assert not bool((mu[0, 260:] != 0).any())            # the call that suffered it is incomplete (and said so)
@@ -189,6 +188,49 @@ def test_handoff_timeout_is_reported_by_the_same_call_and_the_rerun_is_right():
     voc3.set_option("xcm", 1)
     voc3.set_option("xcd_timeout_ms", 20)
     voc3.set_option("xcd_debug_drop_step", 100)
-    with pytest.warns(UserWarning, match="repeated on the fallback path"):
+    with pytest.warns(UserWarning, match="decode repeated"):
         wav3 = driver.generate_checked(voc3, z, spk, seed=9, utt_base=0)
     assert torch.equal(wav3.cpu(), want[0])
+
+
+def test_128_x_32000_bit_equal_to_the_launch_path():
+    """128 utterances of 2 s through the 128 matrix-core slots: the same 4 096 000 samples as the launch-per-step kernels (one
+    run each)."""
+    voc, _ = vocoder()
+    z = synth.randint("xcm/fz128", (128, 100), 512).cuda()
+    spk = (torch.arange(128, device="cuda") % 102)
+    out = {}
+    for name, (xcd, xcm) in {"xcm": (-1, 1), "launch": (0, 0)}.items():
+        voc.set_option("xcd", xcd)
+        voc.set_option("xcm", xcm)
+        wav, mu = voc.generate(z, spk, seed=13, utt_base=0, return_mulaw=True)
+        assert voc.last_path() == (3 if name == "xcm" else 0)
+        out[name] = (wav.cpu(), mu.cpu())
+    voc.set_option("xcd", -1)
+    voc.set_option("xcm", -1)
+    assert torch.equal(out["xcm"][1], out["launch"][1]) and torch.equal(out["xcm"][0], out["launch"][0])
+
+
+def test_2400_consecutive_steps_draw_by_draw_against_the_oracle():
+    """2 400 consecutive steps of two utterances inside a batch of 80 on the matrix-core decoders, every draw checked against
+    the C oracle on the same history (a late-step divergence cannot hide behind 400-step windows)."""
+    voc, sd = vocoder()
+    voc.set_option("xcm", 1)
+    try:
+        B, Tc, steps = 80, 8, 2400
+        z = synth.randint("xcm/lz", (B, Tc), 512)
+        spk = synth.randint("xcm/ls", (B,), 102)
+        wav, mu = voc.generate(z.cuda(), spk.cuda(), seed=21, utt_base=5, return_mulaw=True, max_steps=steps)
+        assert voc.last_path() == 3
+        mu = mu.cpu().numpy()
+        for b in (0, 79):
+            inputs = np.concatenate([[128], mu[b, :steps - 1]])
+            r = oracle.vocoder_generate(sd, z[b].numpy(), int(spk[b]), seed=21, utterance=5 + b, n_steps=steps, inputs=inputs,
+                                        want_logits=True)
+            diff = np.nonzero(r["samples"] != mu[b, :steps])[0]
+            assert len(diff) <= 0.001 * steps, (b, len(diff))
+            for t in diff:
+                pick, sc = oracle.sample_from_logits(r["logits"][t], 21, 5 + b, int(t))
+                assert sc[pick] - sc[int(mu[b, t])] <= 2e-5, (b, int(t))
+    finally:
+        voc.set_option("xcm", -1)

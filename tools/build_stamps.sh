@@ -1,6 +1,6 @@
 #!/bin/sh
 # Debug build of libvqcpc_hip.so with the in-kernel timeline stamps compiled in (build/stamps/, never the shipped library).
-# usage: tools/build_stamps.sh [-DVQCPC_XD_STAMPS | -DVQCPC_PS_STAMPS | -DVQCPC_AR_STAMPS]
+# usage: tools/build_stamps.sh [-DVQCPC_XD_STAMPS | -DVQCPC_AR_STAMPS]
 set -e
 cd "$(dirname "$0")/.."
 DEF=${1:--DVQCPC_XD_STAMPS}

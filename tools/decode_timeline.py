@@ -28,7 +28,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 voc = V.Vocoder(V.ConfVocoder())
 voc.load_state_dict(synth.vocoder_state_dict())
 voc = voc.cuda().eval()
-voc.set_option("persistent", 0)            # the timeline is of the launch-per-step kernels
+voc.set_option("xcd", 0)                   # the timeline is of the launch-per-step kernels
 voc.set_option("fuse_fc2", 0)              # ... one launch per kernel (the stamps are per kernel)
 z = synth.randint("timeline", (B, 4), 512).cuda()                     # 4 codes -> 1280 samples = 8 replays of 160
 spk = torch.arange(B, device="cuda") % 102

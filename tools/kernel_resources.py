@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""One line per kernel of a .hip file: VGPRs, SGPRs, spills, occupancy, LDS (hipcc -Rpass-analysis=kernel-resource-usage).
+"""One line per kernel of a .hip file: VGPRs, SGPRs, spills, scratch, occupancy (hipcc -Rpass-analysis=kernel-resource-usage).
 
-    python tools/kernel_resources.py vectorquantizedcpc_amd/csrc/vocoder.hip [name filter]
+    python tools/kernel_resources.py vectorquantizedcpc_amd/csrc/ar_xcd.hip [name filter]
+
+Rows are keyed on the MANGLED name (kernels in an anonymous namespace demangle to names that all begin with "(anonymous
+namespace)::", and template instantiations share everything in front of their arguments); the demangled name is what is printed.
 """
 import re
 import subprocess
@@ -14,17 +17,24 @@ out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--of
 cur = None
 rows = {}
 for line in out.splitlines():
-    m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (.*?) \[-R", line)
+    m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|"
+                  r"LDS Size \[bytes/block\]): (.*?) \[-R", line)
     if not m:
         continue
     k, v = m.group(1), m.group(2)
     if k == "Function Name":
-        cur = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()
-        cur = re.sub(r"\(.*", "", cur)
+        cur = v
         rows[cur] = {}
     elif cur:
         rows[cur][k.split(" [")[0]] = v
-for name, r in rows.items():
+names = {}
+if rows:
+    dem = subprocess.run(["c++filt"] + list(rows), capture_output=True, text=True).stdout.splitlines()
+    names = dict(zip(rows, dem))
+for mangled, r in rows.items():
+    name = names.get(mangled, mangled)
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", name)          # drop the parameter list, keep template arguments
     if flt in name:
-        print(f"{name:60s} vgpr {r.get('VGPRs'):>4} agpr {r.get('AGPRs'):>3} sgpr {r.get('TotalSGPRs'):>3} "
-              f"spill v{r.get('VGPRs Spill')}/s{r.get('SGPRs Spill')} occ {r.get('Occupancy')} lds {r.get('LDS Size')}")
+        print(f"{name:64s} vgpr {r.get('VGPRs', '?'):>4} agpr {r.get('AGPRs', '?'):>3} sgpr {r.get('TotalSGPRs', '?'):>3} "
+              f"spill v{r.get('VGPRs Spill', '?')}/s{r.get('SGPRs Spill', '?')} scratch {r.get('ScratchSize', '?')} occ {r.get('Occupancy', '?')}")

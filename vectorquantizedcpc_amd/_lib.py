@@ -14,7 +14,7 @@ SYMBOLS = [
     "vqcpc_abi_version", "vqcpc_last_error", "vqcpc_device_count",
     "vqcpc_encoder_create", "vqcpc_encoder_destroy", "vqcpc_encoder_encode",
     "vqcpc_encoder_forward_stats", "vqcpc_encoder_context", "vqcpc_encoder_stage", "vqcpc_encoder_vq_encode", "vqcpc_encoder_set_option",
-    "vqcpc_encoder_check", "vqcpc_vocoder_check", "vqcpc_vocoder_last_path",
+    "vqcpc_encoder_check", "vqcpc_vocoder_check", "vqcpc_vocoder_last_path", "vqcpc_vocoder_last_slots", "vqcpc_vocoder_workspace_bytes", "vqcpc_vocoder_plan",
     "vqcpc_vocoder_create", "vqcpc_vocoder_destroy", "vqcpc_vocoder_generate",
     "vqcpc_vocoder_logits", "vqcpc_vocoder_condition", "vqcpc_vocoder_glue", "vqcpc_vocoder_set_option",
     "vqcpc_vocoder_last_timing", "vqcpc_vocoder_kernel_times",
@@ -75,6 +75,9 @@ def load():
     lib.vqcpc_encoder_check.argtypes = [vp]
     lib.vqcpc_vocoder_check.argtypes = [vp]
     lib.vqcpc_vocoder_last_path.argtypes = [vp]
+    lib.vqcpc_vocoder_last_slots.argtypes = [vp]
+    lib.vqcpc_vocoder_workspace_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.vqcpc_vocoder_plan.argtypes = [i32] * 7 + [C.POINTER(C.c_int), i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     lib.vqcpc_vocoder_create.argtypes = [C.POINTER(VocoderWeights), C.POINTER(vp)]
     lib.vqcpc_vocoder_destroy.argtypes = [vp]
     lib.vqcpc_vocoder_destroy.restype = None

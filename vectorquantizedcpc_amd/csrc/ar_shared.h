@@ -76,13 +76,15 @@ struct Waiter {                      // bounded spinning shared by all sweeps of
     // The wall clock (s_memrealtime: a scalar memory read, ~0.3 us) is only consulted once a wait has spun 64 times: a wait
     // that succeeds quickly never pays for it.  t0 = 0: not taken yet.
     __device__ __forceinline__ void start() { t0 = 0; }
-    // true: give up (deadline passed -- status bit 0 is then set -- or somebody else already gave up)
-    __device__ __forceinline__ bool expired(unsigned spins, int lane) {
+    // true: give up (deadline passed -- status bit 0 is then set -- or somebody else already gave up).  `tagp`: an LDS word with the
+    // call's epoch << 8, so that the status word says WHICH call of the handle gave up; it is read only when the deadline has
+    // passed (kept in a register for the whole call, the tag cost ar_xcd_kernel<2> a VGPR spill inside its sample loop)
+    __device__ __forceinline__ bool expired(unsigned spins, int lane, const int *tagp) {
         if ((spins & 63) != 63) return false;
         const u64 now = __builtin_amdgcn_s_memrealtime();
         if (t0 == 0) t0 = now;
         const bool late = now - t0 > (u64)ticks;
-        if (late && lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // host-mapped: a plain store, no PCIe atomic
+        if (late && lane == 0) __hip_atomic_store(status, (unsigned)*tagp | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // host-mapped: a plain store, no PCIe atomic
         return late || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
     }
 };

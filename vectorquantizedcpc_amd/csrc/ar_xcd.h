@@ -18,7 +18,8 @@ struct XdParams {
     const float *mulaw_tab;   // [n_cls]
     const XdSeg *segs;        // [8 * bxt slots][max_seg]; slot s lives on XCD s % 8 as its local slot s / 8
     unsigned long long *xg;   // exchange area (xd_exchange_bytes), zeroed by xd_launch
-    unsigned *status;         // host-mapped word: 1 = an exchange timed out, 2 = the workgroups were not dealt 32 per XCD
+    unsigned *status;         // host-mapped word: status_tag | 1 = an exchange timed out, | 2 = the workgroups were not dealt 32 per XCD
+    unsigned status_tag;      // the call's epoch << 8 (which call of the handle reported)
     float *wav;               // (rows, Lout) or null
     int64_t *mulaw;           // (rows, Lout) or null
     unsigned long long seed;

@@ -72,8 +72,8 @@ template <int BXT> struct Lds {
     static constexpr int gcq = hold + BXT * 32;           // [BXT][3][32] conditioning row in use
     static constexpr int seg = gcq + BXT * 96;            // int [BXT][8] {index, row, t0, len, utt}
     static constexpr int sinfo = seg + BXT * 8;           // int [BXT][4] {lt, utt, active} of the step in flight
-    static constexpr int ctl = sinfo + BXT * 4;           // int [4] {xcc, rank, ok, abort}
-    static constexpr int total = ctl + 4;
+    static constexpr int ctl = sinfo + BXT * 4;           // int [8] {xcc, rank, ok, abort, the call's status tag}
+    static constexpr int total = ctl + 8;
 };
 
 template <int BXT>
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         if (ok)
             for (int x = 0; x < 8; ++x)
                 if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
-        if (!ok) __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0;
+        if (!ok) __hip_atomic_store(p.status, p.status_tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = (int)p.status_tag;
     }
     __syncthreads();
     const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[0]), rank = __builtin_amdgcn_readfirstlane(s_ctl[1]);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             } else gran_load<BXT, 256>(v1, gh, hoff1);                                                            \
             _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v1[b] >> 32) == tag;      \
             if (__all(ok)) break;                                                                                 \
-            if (wt.expired(spins, lane)) { *s_abort = 1; break; }                                                 \
+            if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }                                                 \
             __builtin_amdgcn_s_sleep(1);                                                                          \
         }                                                                                                         \
         _Pragma("unroll") for (int b = 0; b < BXT; ++b) {                                                         \
@@ -242,8 +242,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
                     const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);
                     float4 wa = wp2[0], wb = wp2[1];                     // first weights and the noise: on their way during the sweep
-                    unsigned r8o = r8;
-                    asm volatile("" : "+v"(r8o));      // opaque: the hoisted address of this read was spilled and reloaded at every step's start
+                    unsigned lno = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id, from the hardware
+                    asm volatile("" : "+v"(lno));      // opaque, and rebuilt: the hoisted address of this read -- then r8, then the lane id
+                    const unsigned r8o = ((lno >> 5) << 2) | (lno & 3u);      // itself -- was spilled to scratch and reloaded at every step
                     const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8o];
                     u64 va[4];
                     wt.start();
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ok &= (unsigned)(va[i] >> 32) == tag;
                         if (__all(ok)) break;
-                        if (wt.expired(spins, lane)) { *s_abort = 1; break; }
+                        if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ac[cw * HF + 64 * i + adst] = __uint_as_float((unsigned)va[i]);
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 for (unsigned spins = 0;; ++spins) {
                     g = ps_load(csrc);
                     if (__all(!cell_on || (unsigned)(g >> 40) == tag)) break;
-                    if (wt.expired(spins, lane)) { *s_abort = 1; break; }
+                    if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
                 }
                 // first argmax per half of 32 lanes (classes ascend with the rank): order-preserving integer image of the score
                 unsigned u = (unsigned)g;

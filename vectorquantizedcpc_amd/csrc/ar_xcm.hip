@@ -89,7 +89,7 @@ struct Lds {
     static constexpr int segst = xs + BX;                 // int [BX][8] {index, row, t0, len, utt, samples into / index of the conditioning frame}
     static constexpr int bqs = segst + BX * 8;            // [3][32] b_hh of the owned units, then b_fc1 [8], b_fc2 [8] of the owned rows
     static constexpr int par = bqs + 112;                   // XmPar: kernel arguments needed once per step or less, read from LDS where they are used (51 SGPRs were spilled)
-    static constexpr int ctl = par + 24;                   // int [12] {xcc, rank, ok, abort, [4] fc1 halves of wave 1 in LDS, [5] its fc2 halves, [7] x_t posted (counts both fc waves)}
+    static constexpr int ctl = par + 24;                   // int [12] {xcc, rank, ok, abort, [4] fc1 halves of wave 1 in LDS, [5] its fc2 halves, [7] x_t posted (counts both fc waves), [10] the call's status tag}
     static constexpr int total = ctl + 12;
 };
 
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         if (ok)
             for (int x = 0; x < 8; ++x)
                 if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
-        if (!ok) __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok) __hip_atomic_store(p.status, p.status_tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         par_set(par, PAR_WAV, (unsigned long long)p.wav); par_set(par, PAR_MULAW, (unsigned long long)p.mulaw); par_set(par, PAR_SEGS, (unsigned long long)p.segs);
         par_set(par, PAR_GCOND, (unsigned long long)p.Gcond); par_set(par, PAR_SEED, p.seed); par_set(par, PAR_GEMB, (unsigned long long)p.Gemb);
         par[PAR_LOUT] = p.Lout; par[PAR_MAXSEG] = p.max_seg; par[PAR_F] = p.F; par[PAR_UPS] = p.upsample; par[PAR_DROP] = p.dbg_drop_step;
-        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = 0; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_ctl[9] = 0;
+        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = 0; s_ctl[5] = 0; s_ctl[6] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_ctl[9] = 0; s_ctl[10] = (int)p.status_tag;
     }
     __syncthreads();
     const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[0]), rank = __builtin_amdgcn_readfirstlane(s_ctl[1]);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) ok &= (td + 768u * (5 * rnd + i) >= (unsigned)(XM_H / 2)) || (v[i].y == tag && v[i].w == tag);
                 if (__all(ok)) break;
-                if (wt.expired(spins, (int)(td & 63u))) { *s_abort = 1; break; }
+                if (wt.expired(spins, (int)(td & 63u), s_abort + 7)) { *s_abort = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 const unsigned ln = opq(lane), aq = ln >> 4, arow = ln & 15u;
                 wt.start();
                 for (unsigned spins = 0; __hip_atomic_load(s_ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 3 * (int)tag; ++spins)
-                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                    if (wt.expired(spins, (int)ln, s_abort + 7) || aborted()) { *s_abort = 1; break; }
                 asm volatile("" ::: "memory");
                 XM_STAMP(0, 18);
                 if (aq == 1 || aq == 2) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) ok &= v[i].y == tag && v[i].w == tag;
                     if (__all(ok)) break;
-                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                    if (wt.expired(spins, (int)ln, s_abort + 7) || aborted()) { *s_abort = 1; break; }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 } else {
                     wt.start();
                     for (unsigned spins = 0; __hip_atomic_load(s_ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 3 * (int)tag; ++spins)
-                        if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                        if (wt.expired(spins, (int)ln, s_abort + 7) || aborted()) { *s_abort = 1; break; }
                     asm volatile("" ::: "memory");
                     XM_STAMP(0, 21);
                     // ---- Gumbel-max candidate of the 8 owned classes for slot arow: lanes aq = 0 (classes 0..3), 1 (4..7)
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                     chunks1(v, gc, c0 * 16u);
                     const bool ok = (v[0].y >> 8) == tag && (v[0].w >> 8) == tag;
                     if (__all(ok)) break;
-                    if (wt.expired(spins, (int)ln) || aborted()) { *s_abort = 1; break; }
+                    if (wt.expired(spins, (int)ln, s_abort + 7) || aborted()) { *s_abort = 1; break; }
                 }
                 {
                     const unsigned u0 = ordered(v[0].x), u1 = ordered(v[0].z);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
             const unsigned td = opq(tid), cu = td >> 4, cs = td & 15u;
             wt.start();
             for (unsigned spins = 0; __hip_atomic_load(s_ctl + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 4 * (int)tag; ++spins) {
-                if (wt.expired(spins, (int)(td & 63u)) || aborted()) { *s_abort = 1; break; }
+                if (wt.expired(spins, (int)(td & 63u), s_abort + 7) || aborted()) { *s_abort = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             asm volatile("" ::: "memory");

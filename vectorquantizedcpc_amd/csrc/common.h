@@ -67,6 +67,6 @@ int vq_lstm_plan_create(const float *w_ih, const float *w_hh, const float *b_ih,
 void vq_lstm_plan_destroy(LstmPlan *p);
 // x (B, T, D) device -> out (B, T, H) device, zero initial state.
 int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream_t s);
-int vq_lstm_set_persistent(LstmPlan *p, int value);
+int vq_lstm_set_persistent(LstmPlan *p, int value);                  // -1 auto (one utterance: the resident scan), 0 one launch per time step
 int vq_lstm_set_debug(LstmPlan *p, int drop_step, int timeout_ms);   // tests of the abort path
-int vq_lstm_check(LstmPlan *p);            // after the caller's sync: did the resident scan of the last call time out?   // -1 auto (one utterance: the resident scan), 0 one launch per time step
+int vq_lstm_check(LstmPlan *p);            // after the caller's sync: did the resident scan of the last call time out?

@@ -12,7 +12,7 @@
 // boundary; the per-sample kernels are replayed from a hipGraph.  Two launches per sample: fc1, then ONE launch that
 // carries fc2 + draw of the previous sample in front of the GRU step (W_hh h does not depend on the drawn sample; the
 // candidates reach the GRU's gate waves through in-kernel granules).  A call on a single utterance runs on the
-// persistent decoder instead (ar_persist_kernel: resident workgroups, weights in registers, no launches per sample).
+// per-XCD resident decoders instead (ar_xcd.hip / ar_xcm.hip: weights in registers, no launches per sample).
 #include "common.h"
 #include "ar_shared.h"
 #include "ar_xcd.h"
@@ -985,56 +985,12 @@ __global__ __launch_bounds__(256) void ar_fc2_kernel(ArModel m, const ArCall *__
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent single-utterance decoder (BASELINE configs[2]: Vocoder.generate on ONE utterance).
-//
-// One utterance cannot amortise the per-sample kernel boundaries (3 x 1.5 us) nor the re-fetch of 10.8 MB of weights
-// per step that they force (L2 does not keep lines across launches).  Here 64 workgroups stay resident for the whole
-// call and hold ALL weights in registers: workgroup j owns hidden units 14 j .. 14 j + 13 (42 gate rows of W_hh),
-// 4 rows of fc1 and 4 classes of fc2.  The three all-to-all mixes of a sample step (h_t, a_t, the 64 draw candidates)
-// are exchanged in-kernel as 8-byte {tag, value} granules (tag = step + 1) written with agent-scope relaxed atomics
-// (sc1 write-through stores) and swept by ONE wave per workgroup with agent-scope relaxed loads -- the data is the flag
-// (MI355X_MICROARCH.md "Valid forms", R2; cdna_hip_programming.md Guideline 16).  Single-buffered granules are safe:
-// nobody can produce step t+1's value of a word before every workgroup has consumed step t's (each later product
-// depends, through the next exchange, on every workgroup having finished the sweep that reads it).
-//
-// Arithmetic is BIT-IDENTICAL to the launch-per-step kernels: a v_mfma_f32_16x16x4_f32 chain is a sequence of fp32
-// fmas in a fixed k order (two accumulators per K quarter, x/z and y/w components of the fragment), so each lane here
-// runs one such chain with explicit fmaf and the partial sums are combined in the same order (a0 + a1, then
-// ((q0 + q1) + q2) + q3); cell update, fc epilogues, Gumbel-max draw are the same code.  Hence an utterance decoded
-// alone still equals the same utterance inside a batch bit for bit.
-//
-// Roles (512 threads): wave 0 = fc1 (lanes 0..31: 4 rows x 8 chains) and fc2 + draw (lanes 32..63: 4 classes x 8
-// chains); waves 1..6 = the 336 W_hh chains (42 rows x 8); wave 7 = service wave: sweeps the granules, merges the
-// candidates, runs the cell update of the 14 units and publishes.  Two workgroup barriers per sample.
-// Every spin is bounded (wall clock); a timeout raises an abort flag that every workgroup polls, and all waves leave.
+// fp32 fma chains on the vector ALU, bit-identical to the v_mfma_f32_16x16x4_f32 schedule of the launch-per-step kernels
+// (a chain is a sequence of fp32 fmas in a fixed k order: two accumulators per K quarter, the x/z and y/w components of
+// the fragment; partial sums combined a0 + a1, then ((q0 + q1) + q2) + q3) -- used by the resident context scan below.
+// (Round 2's 64-workgroup persistent single-utterance decoder, ar_persist_kernel, lived here; the per-XCD decoders of
+// ar_xcd.hip replaced it in round 3 -- 2.6 us per sample against 4.95 -- and it was removed in round 4.)
 // ------------------------------------------------------------------------------------------
-#define PS_NB 64
-// Timeline stamps of workgroup PS_STAMP_BLK (100 MHz wall clock), steps 256..383, for tools/persist_timeline.py: compiled
-// in only with -DVQCPC_PS_STAMPS (a debug build under build/stamps/, never the shipped library).
-#ifdef VQCPC_PS_STAMPS
-#define PS_STAMP_BLK 5
-__device__ unsigned long long g_ps_stamps[128 * 12];
-#define PS_STAMP(i) do { if (blk == PS_STAMP_BLK && (lane & 63) == 0 && t >= 256 && t < 384) \
-        g_ps_stamps[(t - 256) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-extern "C" int vqcpc_debug_ps_stamps(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps)) == hipSuccess ? 0 : -1;
-}
-#else
-#define PS_STAMP(i) do { } while (0)
-#endif
-
-struct PersistP {
-    const float *w_hh, *w_fc1, *b_fc1, *w_fc2, *b_fc2;
-    const float4 *Gemb4, *bh4;
-    const float *Gcond;               // [F][3Hr] conditioning rows of this utterance (W_ih[:, de:] cond + b_ih)
-    const float *mulaw_tab;
-    u64 *gh, *ga, *gc;                // granules of h_t, a_t, the candidates: [PS_NB][PS_PAD] each (a line per workgroup)
-    unsigned *abort_flag;             // pinned HOST memory (system-scope accesses): the host reads it without a HIP call
-    float *wav; int64_t *mulaw;
-    int n_steps, upsample, F;
-    unsigned utt; u64 seed;
-};
-
 // index of h[k] in the LDS copy: inside each 16-block, [component k % 4][k / 4 % 4], so that a chain reads the four
 // k of one MFMA as one 16-byte LDS word
 __device__ __forceinline__ int ps_perm(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -1066,25 +1022,6 @@ __device__ __forceinline__ float ps_combine(float acc, int lane) {
     const float q2 = PS_DPP(q, 0x104);                 // row_shl:4: lane + 4
     const float q3 = PS_DPP(q, 0x106);                 // row_shl:6: lane + 6
     return ((q + q1) + q2) + q3;
-}
-
-// First argmax over the 64 lanes of (score, class), classes ascending with the lane: max of an order-preserving integer
-// image of the score by four DPP steps inside each row of 16 lanes and four readlanes across rows, then the first lane
-// that holds it (six __shfl_xor pairs -- ds_bpermute round trips -- took ~0.5 us of every sample step).
-__device__ __forceinline__ int ps_argmax64(float score, int cls) {
-    unsigned u = __float_as_uint(score);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    unsigned m = u;
-    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));    // row_half_mirror
-    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false));    // row_mirror
-    const unsigned m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 16),
-                   m2 = __builtin_amdgcn_readlane(m, 32), m3 = __builtin_amdgcn_readlane(m, 48);
-    const unsigned best = max(max(m0, m1), max(m2, m3));
-    const unsigned long long hit = __ballot(u == best);
-    const int first = __ffsll((long long)hit) - 1;
-    return __builtin_amdgcn_readlane(cls, first);
 }
 
 // Every workgroup's granules start on a 128-byte line of their own (16 granules): lines shared by writers on different
@@ -1233,196 +1170,6 @@ static int lstm_persist_launch(LstmPlan *p, int T, float *out, hipStream_t s) {
     return VQCPC_OK;
 }
 
-template <int SW>     // Hr = 64 SW; each of the 64 workgroups owns SW hidden units; Hf = n_cls = 256
-__global__ __launch_bounds__(512) void ar_persist_kernel(PersistP p) {
-    constexpr int Hr = 64 * SW, UPB = SW, NG = 3 * UPB * 8, Hf = 256, NC = 256, RPB = Hf / PS_NB;
-    __shared__ float4 gemb[NC * UPB];                                   // this workgroup's slice of the sample-embedding table
-    __shared__ __attribute__((aligned(16))) float hbuf[Hr];            // h_t, ps_perm order
-    __shared__ __attribute__((aligned(16))) float a1buf[Hf];           // a_t, ps_perm order
-    __shared__ float gsum[3 * UPB];                                     // W_hh h_{t-1} of the owned rows [gate][unit]
-    __shared__ int s_abort[2];                                          // [t & 1]: written by the service wave during step t only, so a
-                                                                        // wave still reading step t-1's verdict never sees step t's
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
-    const int n = p.n_steps;
-
-    // ---- resident state: weights into registers, table slice into LDS
-    float w[8 * SW];
-    const int kw = (lane & 7) >> 1, c0 = lane & 1;
-    int row_local = 0;
-    bool gru_lane = false;
-    if (wave == 0) {
-        if (lane < 32) { row_local = lane >> 3; ps_load_weights<SW>(p.w_fc1 + (size_t)(RPB * blk + row_local) * Hr, kw, c0, w); }
-        else {
-            row_local = (lane - 32) >> 3;
-            float w2[8 * 4];
-            ps_load_weights<4>(p.w_fc2 + (size_t)(RPB * blk + row_local) * Hf, kw, c0, w2);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) w[i] = w2[i];
-        }
-    } else if (wave < 7) {
-        const int c = tid - 64;
-        gru_lane = c < NG;
-        row_local = gru_lane ? c >> 3 : 0;                                              // gate * UPB + unit
-        const int gate = row_local / UPB, ul = row_local - gate * UPB;
-        ps_load_weights<SW>(p.w_hh + (size_t)(gate * Hr + UPB * blk + ul) * Hr, kw, c0, w);
-    }
-    for (int e = tid; e < NC * UPB; e += 512) {
-        const int cls = e / UPB, unit = UPB * blk + (e - cls * UPB);
-        gemb[e] = p.Gemb4[((size_t)cls * (Hr >> 2) + (unit >> 2)) * 4 + (unit & 3)];
-    }
-    if (tid == 0) { s_abort[0] = 0; s_abort[1] = 0; }
-    // service-wave registers: biases / conditioning / previous state of unit `lane` (lanes < UPB)
-    const int my_unit = UPB * blk + (lane < UPB ? lane : 0);
-    const float4 bq = p.bh4[(my_unit >> 2) * 4 + (my_unit & 3)];
-    float4 gcq = make_float4(0.f, 0.f, 0.f, 0.f);
-    float hold = 0.f;
-    const float fc_bias = wave == 0 ? (lane < 32 ? p.b_fc1[RPB * blk + row_local] : p.b_fc2[RPB * blk + row_local]) : 0.f;
-    ps_barrier();
-
-    bool dead = false;                                    // service wave: an exchange timed out
-    bool aborted = false;
-    for (int t = 0; t < n; ++t) {
-        const unsigned tag = (unsigned)t + 1u;
-        volatile int *ab = &s_abort[t & 1];
-        if (wave == 7) {
-            // ---- x_{t-1} from the 64 candidates of step t-1, then the cell update of the owned units
-            __builtin_amdgcn_s_setprio(3);
-            PS_STAMP(0);
-            int x = NC / 2;
-            if (t > 0 && !dead) {
-                unsigned v[1];
-                u64 g = 0;
-                {   // candidates carry (tag << 8 | class) in the high word and the score in the low word
-                    const u64 t0 = __builtin_amdgcn_s_memrealtime();
-                    for (unsigned spins = 0;; ++spins) {
-                        g = ps_load(p.gc + lane * PS_PAD);
-                        if (__all((unsigned)(g >> 40) == (unsigned)t)) break;
-                        if ((spins & 63) == 63) {
-                            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;
-                            if (late || __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
-                                if (late && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                dead = true;
-                                break;
-                            }
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                (void)v;
-                x = ps_argmax64(__uint_as_float((unsigned)g), (int)((g >> 32) & 255u));    // higher score, then lower class
-                if (blk == 0 && lane == 0 && !dead) {                    // network_vocoder.py:78 output: sample t-1
-                    if (p.wav) p.wav[t - 1] = p.mulaw_tab[x];
-                    if (p.mulaw) p.mulaw[t - 1] = x;
-                }
-            }
-            PS_STAMP(1);                                                 // x known
-            if (!dead) {
-                if (t % p.upsample == 0 && lane < UPB) {                 // next conditioning frame (once per hop)
-                    const int f = t / p.upsample < p.F ? t / p.upsample : p.F - 1;
-                    const float *gcp = p.Gcond + (size_t)f * 3 * Hr + my_unit;
-                    gcq = make_float4(gcp[0], gcp[Hr], gcp[2 * Hr], 0.f);
-                }
-                if (lane < UPB) {
-                    const float4 eq = gemb[x * UPB + lane];
-                    const bool first = t == 0;
-                    const float gr = first ? 0.f : gsum[lane], gz = first ? 0.f : gsum[UPB + lane], gn = first ? 0.f : gsum[2 * UPB + lane];
-                    const float r = sigmoidf_((eq.x + gcq.x) + (gr + bq.x));
-                    const float z = sigmoidf_((eq.y + gcq.y) + (gz + bq.y));
-                    const float nn = tanhf((eq.z + gcq.z) + r * (gn + bq.z));
-                    hold = (1.0f - z) * nn + z * hold;
-                    ps_store(p.gh + blk * PS_PAD + lane, ((u64)tag << 32) | __float_as_uint(hold));
-                }
-                PS_STAMP(2);                                             // own h published
-                // ---- gather h_t
-                unsigned hv[SW];
-                if (ps_sweep<SW>(p.gh, lane, UPB, tag, hv, p.abort_flag)) {
-#pragma unroll
-                    for (int j = 0; j < SW; ++j) hbuf[ps_perm(lane + 64 * j)] = __uint_as_float(hv[j]);
-                } else dead = true;
-            }
-            if (dead) *ab = 1;
-            PS_STAMP(3);                                                 // h_t gathered
-            ps_barrier();                                                // A: h_t in LDS
-            PS_STAMP(4);
-            if (!dead) {
-                unsigned av[Hf / 64];
-                if (ps_sweep<Hf / 64>(p.ga, lane, RPB, tag, av, p.abort_flag)) {
-#pragma unroll
-                    for (int j = 0; j < Hf / 64; ++j) a1buf[ps_perm(lane + 64 * j)] = __uint_as_float(av[j]);
-                } else { dead = true; *ab = 1; }
-            }
-            PS_STAMP(5);                                                 // a_t gathered
-            ps_barrier();                                                // B: a_t and W_hh h_t in LDS
-            PS_STAMP(6);
-        } else if (wave == 0) {
-            float gum = 0.f;
-            if (lane >= 32 && (lane & 7) == 0) {                         // the draw's noise does not depend on the data
-                const int cls = RPB * blk + row_local;
-                const unsigned wd = philox_word((unsigned)t, p.utt, (unsigned)(cls >> 2), (unsigned)p.seed, (unsigned)(p.seed >> 32), cls & 3);
-                gum = gumbel_from_word(wd);
-            }
-            ps_barrier();                                                // A
-            __builtin_amdgcn_s_setprio(3);                               // fc1 / fc2 are on the critical path; the W_hh chains
-            if (*ab == 0 && lane < 32) {                                 // that share the SIMDs are not
-                const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
-                float v = ps_combine(acc, lane);
-                v += fc_bias;
-                if ((lane & 7) == 0) ps_store(p.ga + blk * PS_PAD + row_local, ((u64)tag << 32) | __float_as_uint(v > 0.f ? v : 0.f));
-            }
-            PS_STAMP(7);                                                 // fc1 rows published
-            ps_barrier();                                                // B
-            if (*ab == 0 && lane >= 32) {
-                float w2[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) w2[i] = w[i];
-                const float acc = ps_chain<4>(w2, (const float4 *)a1buf, kw, c0);
-                float v = ps_combine(acc, lane);
-                v += fc_bias;
-                float sc = v + gum;
-                int cls = RPB * blk + row_local;
-#pragma unroll
-                for (int off = 8; off < 32; off <<= 1) {                 // first max over the 4 classes (lanes 32, 40, 48, 56)
-                    const float os = __shfl_xor(sc, off);
-                    const int oc = __shfl_xor(cls, off);
-                    if (os > sc || (os == sc && oc < cls)) { sc = os; cls = oc; }
-                }
-                if (lane == 32) ps_store(p.gc + blk * PS_PAD, ((u64)((tag << 8) | (unsigned)cls) << 32) | __float_as_uint(sc));
-            }
-            __builtin_amdgcn_s_setprio(0);
-            PS_STAMP(8);                                                 // candidate published
-        } else {
-            ps_barrier();                                                // A
-            if (*ab == 0) {
-                const float acc = ps_chain<SW>(w, (const float4 *)hbuf, kw, c0);
-                const float v = ps_combine(acc, lane);
-                if (gru_lane && (lane & 7) == 0) gsum[row_local] = v;
-            }
-            if (wave == 1) PS_STAMP(9);                                  // W_hh h_t chains done
-            ps_barrier();                                                // B
-        }
-        if (*ab != 0) { aborted = true; break; }                         // read after barrier B: uniform for the workgroup
-    }
-    // ---- the last sample is still only candidates
-    if (wave == 7 && blk == 0 && n > 0 && !aborted) {
-        u64 g = 0;
-        bool ok = true;
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
-        for (unsigned spins = 0;; ++spins) {
-            g = ps_load(p.gc + lane * PS_PAD);
-            if (__all((unsigned)(g >> 40) == (unsigned)n)) break;
-            if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
-                                       __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const int cls = ps_argmax64(__uint_as_float((unsigned)g), (int)((g >> 32) & 255u));
-        if (ok && lane == 0) {
-            if (p.wav) p.wav[n - 1] = p.mulaw_tab[cls];
-            if (p.mulaw) p.mulaw[n - 1] = cls;
-        }
-        if (!ok && lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 __global__ void ar_advance_kernel(ArCall *c, int n) {
     c->t_base += n;
     if (c->hall && c->t_base - c->hall_t0 >= c->CH) c->hall_t0 += c->CH;      // next chunk of the teacher-forced scan
@@ -1498,9 +1245,11 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
 }
 
 // Vocoder glue (network_vocoder.py:73-77): series[b, t2, :dz] = code_emb[idx[b, t2/2]], [dz:] = spk_emb[spk[b]]
+// An index outside its table (nn.Embedding raises IndexError, network_vocoder.py:73,75) is clamped for the read and reported through
+// the handle's host-mapped status word (bit 2; vqcpc_vocoder_check): no read-back of the indices on the host, no synchronisation.
 __global__ void glue_kernel(const int64_t *__restrict__ idx, const int64_t *__restrict__ spk,
                             const float *__restrict__ ce, const float *__restrict__ se, float *__restrict__ out,
-                            int B, int Tc, int dz, int ds, int n_codes, int n_spk) {
+                            int B, int Tc, int dz, int ds, int n_codes, int n_spk, unsigned *status, unsigned status_tag) {
     const int F = dz + ds;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * 2 * Tc * F) return;
@@ -1509,10 +1258,12 @@ __global__ void glue_kernel(const int64_t *__restrict__ idx, const int64_t *__re
     const int t2 = (int)(r % (2 * Tc)), b = (int)(r / (2 * Tc));
     if (f < dz) {
         long long z = idx[(size_t)b * Tc + t2 / 2];
+        if ((z < 0 || z >= n_codes) && f == 0 && status) __hip_atomic_fetch_or(status, status_tag | 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         z = z < 0 ? 0 : (z >= n_codes ? n_codes - 1 : z);
         out[i] = ce[(size_t)z * dz + f];
     } else {
         long long sp = spk[b];
+        if ((sp < 0 || sp >= n_spk) && f == dz && t2 == 0 && status) __hip_atomic_fetch_or(status, status_tag | 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         sp = sp < 0 ? 0 : (sp >= n_spk ? n_spk - 1 : sp);
         out[i] = se[(size_t)sp * ds + (f - dz)];
     }
@@ -1591,13 +1342,21 @@ struct vqcpc_vocoder {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf series, gi, out0, cond, gcond, hseq, len;
     DevBuf hall, a1c;                    // teacher-forced scan: h_t and fc1 outputs of one chunk
-    DevBuf px;                           // persistent single-utterance decoder: granules
-    unsigned *abort_host = nullptr;      // its abort flag: pinned host memory the kernel writes and the host reads without a HIP call
+    unsigned *abort_host = nullptr;      // the handle's status word: pinned host memory the kernels write and the host reads without a HIP call
+    unsigned *abort_dev = nullptr;       // the device's view of it
     HostStage stage;
     float *w_hh = nullptr;               // plain (3Hr, Hr) copy of W_hh for it
     int fuse_fc2 = 1;                    // fc2 + draw of step t-1 and the GRU step t share one launch
-    int persistent = -1;                 // -1 auto (single utterance, reference dimensions), 0 never, 1 = auto as well
-    bool persist_pending = false;        // a persistent decode is in flight: its abort flag has not been read yet
+    bool persist_pending = false;        // a call with in-kernel hand-offs is in flight: its status word has not been read behind a sync yet
+    unsigned epoch = 0;                  // calls of run_ar so far: the resident decoders tag the status word with it
+    int last_slots = 0;                  // decode slots the last call's loop actually used
+    // Fallback policy.  A placement miss (status 2: the 256 workgroups were not dealt 32 per XCD -- another kernel held CUs) wrote
+    // nothing and is transient: the call is reported, the handle keeps its options, the caller repeats; only the second miss in
+    // a row switches the resident decoders off.  A timeout (status 1) switches the in-kernel hand-offs off at once and the
+    // handle re-arms itself after REARM_CLEAN clean calls (or when the option is set again).
+    int placement_misses = 0;
+    bool fell_back = false;
+    int saved_xcd = -1, saved_fuse_fc2 = 1, clean_calls = 0;
     // one resident decoder per XCD (ar_xcd.hip): -1 auto, 0 never, 1 whenever the dimensions allow
     int handoff_timeout_ms = 250;        // bound of the candidate waits of the fused fc2 || GRU launch
     int handoff_debug_drop_step = -1;    // tests: one fc2 team skips its publish at this step
@@ -1656,7 +1415,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->w_hh) (void)hipFree(v->w_hh);
     if (v->Gemb4) (void)hipFree(v->Gemb4);
     if (v->bh4) (void)hipFree(v->bh4);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->px, &v->xd_x, &v->xd_segs};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -1728,6 +1487,7 @@ static int vocoder_create_impl(const vqcpc_vocoder_weights *w, vqcpc_vocoder *v)
     for (auto &g : v->grp) HIP_TRY(hipMalloc((void **)&g.call, sizeof(ArCall)));
     HIP_TRY(hipHostMalloc((void **)&v->abort_host, 64, hipHostMallocMapped));
     *v->abort_host = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void **)&v->abort_dev, v->abort_host, 0));
     HIP_TRY(hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
@@ -1789,11 +1549,6 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
         v->fuse_fc2 = value != 0;
         return VQCPC_OK;
     }
-    if (!strcmp(name, "persistent")) {
-        VQ_REQUIRE(value >= -1 && value <= 1, "persistent must be -1 (auto), 0 or 1");
-        v->persistent = value;
-        return VQCPC_OK;
-    }
     if (!strcmp(name, "handoff_timeout_ms")) {
         VQ_REQUIRE(value >= 1 && value <= 10000, "handoff_timeout_ms must be in [1, 10000]");
         if (value != v->handoff_timeout_ms) clear_graphs(v);
@@ -1808,6 +1563,7 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
     if (!strcmp(name, "xcd")) {
         VQ_REQUIRE(value >= -1 && value <= 1, "xcd must be -1 (auto), 0 or 1");
         v->xcd = value;
+        v->fell_back = false; v->placement_misses = 0;
         return VQCPC_OK;
     }
     if (!strcmp(name, "xcd_slots")) {
@@ -1858,25 +1614,56 @@ extern "C" int vqcpc_vocoder_set_option(vqcpc_vocoder *v, const char *name, int 
 }
 
 static void clear_graphs(vqcpc_vocoder *v);
-// After the stream that carried a persistent decode has been synchronised: did an in-kernel exchange time out?
-static int persist_check(vqcpc_vocoder *v) {
+// Did an in-kernel hand-off of an earlier call give up?  The status word is host-mapped (no HIP call).  `synced`: the caller has
+// synchronised the stream that carried the calls (vqcpc_vocoder_check's contract), so a zero word clears every call in flight;
+// without it (the start of the next call) only a word that is already set is acted on -- nothing is cleared before a sync.
+constexpr int REARM_CLEAN = 16;
+static int persist_check(vqcpc_vocoder *v, bool synced) {
     if (!v->persist_pending) return VQCPC_OK;
-    const unsigned flag = *(volatile unsigned *)v->abort_host;        // written by the kernel on a timeout; no HIP call
+    const unsigned flag = *(volatile unsigned *)v->abort_host;        // written by the kernel; no HIP call
+    if (flag == 0) {
+        if (synced) {
+            v->persist_pending = false;
+            v->placement_misses = 0;
+            if (v->fell_back && ++v->clean_calls >= REARM_CLEAN) {     // re-arm: the cause (a co-tenant kernel, a hung peer) is probably gone
+                v->fell_back = false;
+                v->xcd = v->saved_xcd;
+                if (v->saved_fuse_fc2 && !v->fuse_fc2) { v->fuse_fc2 = 1; clear_graphs(v); }
+            }
+        }
+        return VQCPC_OK;
+    }
+    *(volatile unsigned *)v->abort_host = 0u;
     v->persist_pending = false;
-    if (flag != 0) {
-        *(volatile unsigned *)v->abort_host = 0u;
-        v->persistent = 0;                 // e.g. the workgroups could not all be resident: no in-kernel exchanges from now on
-        v->xcd = 0;
-        if (v->fuse_fc2) { v->fuse_fc2 = 0; clear_graphs(v); }
-        if (flag & 2u)
-            vq_set_error("decode not run: the per-XCD decoder's workgroups were not dealt 32 to each XCD (no output was written); "
-                         "this handle now uses one launch per kernel and step -- call again (set_option xcd to re-enable)");
-        else
-            vq_set_error("decode aborted: an in-kernel exchange timed out (outputs of that call are incomplete); this handle now "
-                         "uses one launch per kernel and step -- call again (set_option xcd / persistent / fuse_fc2 to re-enable)");
+    const unsigned code = flag & 0xffu, ep = flag >> 8;
+    char which[64];
+    if (ep) snprintf(which, sizeof which, "call #%u of this handle", ep);
+    else snprintf(which, sizeof which, "an earlier call of this handle");
+    if (code & 4u) {
+        vq_set_error("index out of range in self (%s): a code index or speaker id outside its embedding table (network_vocoder.py:73,75)", which);
+        return VQCPC_ERR_INVALID;
+    }
+    if (code & 2u) {
+        v->placement_misses += 1;
+        if (v->placement_misses >= 2) {
+            if (!v->fell_back) { v->saved_xcd = v->xcd; v->saved_fuse_fc2 = v->fuse_fc2; }
+            v->fell_back = true; v->clean_calls = 0;
+            v->xcd = 0;
+            vq_set_error("decode not run (%s): the resident decoders' workgroups were not dealt 32 to each XCD, twice in a row (no output was "
+                         "written; the GPU is probably shared) -- this handle now uses one launch per kernel and step; repeat the call", which);
+        } else {
+            vq_set_error("decode not run (%s): the resident decoders' workgroups were not dealt 32 to each XCD (no output was written; "
+                         "another kernel held compute units) -- repeat the call", which);
+        }
         return VQCPC_ERR_HIP;
     }
-    return VQCPC_OK;
+    if (!v->fell_back) { v->saved_xcd = v->xcd; v->saved_fuse_fc2 = v->fuse_fc2; }
+    v->fell_back = true; v->clean_calls = 0;
+    v->xcd = 0;
+    if (v->fuse_fc2) { v->fuse_fc2 = 0; clear_graphs(v); }
+    vq_set_error("decode aborted (%s): an in-kernel exchange timed out (outputs of that call are incomplete); this handle now uses one launch "
+                 "per kernel and step, and re-arms after %d clean calls or set_option xcd / fuse_fc2 -- repeat the call", which, REARM_CLEAN);
+    return VQCPC_ERR_HIP;
 }
 
 extern "C" int vqcpc_vocoder_last_path(vqcpc_vocoder *v) {
@@ -1886,12 +1673,26 @@ extern "C" int vqcpc_vocoder_last_path(vqcpc_vocoder *v) {
 
 extern "C" int vqcpc_vocoder_check(vqcpc_vocoder *v) {
     VQ_REQUIRE(v, "vqcpc_vocoder_check: null argument");
-    return persist_check(v);
+    return persist_check(v, true);
+}
+
+extern "C" int vqcpc_vocoder_last_slots(vqcpc_vocoder *v) {
+    return v ? v->last_slots : -1;
+}
+
+extern "C" int vqcpc_vocoder_workspace_bytes(vqcpc_vocoder *v, uint64_t *bytes) {
+    VQ_REQUIRE(v && bytes, "vqcpc_vocoder_workspace_bytes: null argument");
+    uint64_t n = 0;
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
+    for (DevBuf *b : bufs) n += b->cap;
+    for (auto &G : v->grp) { DevBuf *gb[] = {&G.har, &G.a1, &G.cand_s, &G.cand_k, &G.gcur, &G.candg, &G.slot_tab, &G.cur}; for (DevBuf *b : gb) n += b->cap; }
+    *bytes = n;
+    return VQCPC_OK;
 }
 
 extern "C" int vqcpc_vocoder_last_timing(vqcpc_vocoder *v, float *loop_ms, int *n_steps) {
     VQ_REQUIRE(v && loop_ms && n_steps, "vqcpc_vocoder_last_timing: null argument");
-    TRY(persist_check(v));
+    TRY(persist_check(v, true));
     HIP_TRY(hipEventElapsedTime(loop_ms, v->ev0, v->ev1));
     *n_steps = v->last_steps;
     return VQCPC_OK;
@@ -1910,7 +1711,8 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
     TRY(v->hseq.reserve(2 * hsz));
     const size_t ng = rows * F;
     hipLaunchKernelGGL(glue_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, idx, spk, v->code_emb,
-                       v->spk_emb, v->series.as<float>(), B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers);
+                       v->spk_emb, v->series.as<float>(), B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers, v->abort_dev, v->epoch << 8);
+    v->persist_pending = true;            // an index outside its table is reported through the status word
     for (int l = 0; l < 2; ++l) {
         const float *xin = l == 0 ? v->series.as<float>() : v->out0.as<float>();
         const int I = l == 0 ? F : dl;
@@ -2017,6 +1819,70 @@ static int tf_chunk_gemms(vqcpc_vocoder *v, int B, int Ts, int CH, int chunk, fl
     return VQCPC_OK;
 }
 
+// Which decode loop takes a call, and the resident decoders' slot schedule: pure host arithmetic (no HIP call), so that it can be
+// tested without a GPU (vqcpc_vocoder_plan).  samples[b] = samples utterance b produces; `order` = utterances longest first.
+// path 2 / 3: the per-XCD decoders (VALU / matrix-core form) through `xs` slots, slot q running lists[q] back to back;
+// path 0: the launch-per-step kernels.  A slot's schedule must stay below 2^24 - 1 steps (the candidate tag of step t is
+// (t + 1) << 8 in 32 bits): a call `auto` would have put on the resident decoders then takes the launch path; asked for by name
+// (xcd / xcm = 1) it is an error (returns false).
+struct DecodePlan {
+    int path = 0, xs = 0, bxt = 0;
+    long longest = 0;
+    std::vector<std::vector<XdSeg>> lists;
+    std::vector<long> xend;
+};
+struct PlanOpts { int xcd, xcm, xcm_min, xcm_max, xcd_slots, xcm_slots, n_slots; bool supported; };
+static bool plan_decode(const PlanOpts &o, const int *samples, const unsigned *utt, const std::vector<int> &order, DecodePlan &pl) {
+    int nz = 0;
+    long max_len = 0;
+    for (int row : order) { nz += samples[row] > 0; max_len = samples[row] > max_len ? samples[row] : max_len; }
+    pl = DecodePlan{};
+    // auto: up to xcm_min (68) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
+    // against 3.4 / 4.7 M on the launch path), from there to xcm_max the matrix-core form through its 128 slots, above that the
+    // launch-per-step kernels; `xcd` = 0 turns both off, = 1 asks for the VALU form whatever the count
+    const int in_flight = o.n_slots > 0 && o.n_slots < nz ? o.n_slots : nz;
+    const bool xcm_wanted = o.xcd != 0 && (o.xcm == 1 || (o.xcm == -1 && o.xcd == -1 && in_flight > o.xcm_min && in_flight < o.xcm_max));
+    const bool xcd_wanted = xcm_wanted || o.xcd == 1 || (o.xcd == -1 && in_flight <= o.xcm_min);
+    if (!xcd_wanted || !o.supported || max_len <= 0 || nz <= 0) return true;
+    int xs = xcm_wanted ? o.xcm_slots : (o.xcd_slots < 1 ? 1 : o.xcd_slots);
+    if (o.n_slots > 0 && o.n_slots < xs) xs = o.n_slots;
+    if (nz < xs) xs = nz;
+    const int bxt = xcm_wanted ? XM_BX : xd_pick_bxt((xs + 7) / 8);
+    pl.xend.assign(xs, 0);
+    pl.lists.assign(xs, {});
+    for (int row : order) {
+        const int len = samples[row];
+        if (len <= 0) continue;
+        int best = 0;
+        for (int q = 1; q < xs; ++q) if (pl.xend[q] < pl.xend[best]) best = q;
+        pl.lists[best].push_back(XdSeg{row, (int)pl.xend[best], len, utt ? utt[row] : (unsigned)row});
+        pl.xend[best] += len;
+    }
+    for (int q = 0; q < xs; ++q) pl.longest = pl.xend[q] > pl.longest ? pl.xend[q] : pl.longest;
+    const bool fits = bxt > 0 && pl.longest + 1 < (1L << 24);
+    if (!fits) {
+        pl.lists.clear(); pl.xend.clear();
+        return !(o.xcd == 1 || o.xcm == 1);
+    }
+    pl.path = xcm_wanted ? 3 : 2; pl.xs = xs; pl.bxt = bxt;
+    return true;
+}
+
+extern "C" int vqcpc_vocoder_plan(int xcd, int xcm, int xcm_min, int xcm_max, int xcd_slots, int xcm_slots, int slots,
+                                  const int *n_samples, int B, int *path, int *slots_used, int64_t *longest) {
+    VQ_REQUIRE(n_samples && B > 0 && path && slots_used && longest, "vqcpc_vocoder_plan: bad argument");
+    std::vector<int> order(B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
+    DecodePlan pl;
+    const PlanOpts o{xcd, xcm, xcm_min < 0 ? 68 : xcm_min, xcm_max < 0 ? 512 : xcm_max, xcd_slots <= 0 ? 8 * XD_MAX_BX : xcd_slots,
+                     xcm_slots <= 0 ? 8 * XM_BX : xcm_slots, slots, true};
+    VQ_REQUIRE(plan_decode(o, n_samples, nullptr, order, pl), "vocoder: a decode slot's schedule does not fit the resident decoders "
+               "(< 2^24 - 1 samples); use more slots or xcd = -1");
+    *path = pl.path; *slots_used = pl.path ? pl.xs : (slots > 0 && slots < B ? slots : B); *longest = pl.longest;
+    return VQCPC_OK;
+}
+
 // Shared driver of generate() and logits().
 static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int B, int Tc, const int *n_codes_host,
                   const int64_t *inputs, int Ts, unsigned long long seed, unsigned utt_base,
@@ -2076,7 +1942,9 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     const int n_grp = split ? 2 : 1;
     const int tiles[2] = {split ? (nbt + 1) / 2 : nbt, split ? nbt / 2 : 0};
     const int slot0[2] = {0, tiles[0] * 16};
-    TRY(persist_check(v));                // did an earlier persistent decode report a timeout?
+    TRY(persist_check(v, false));         // has an earlier call's hand-off reported already?  (nothing is cleared without a sync)
+    v->epoch = (v->epoch + 1u) & 0xffffffu;
+    if (v->epoch == 0) v->epoch = 1;
     TRY(v->len.reserve(lens.size() * sizeof(int)));
     std::vector<ArSlot> table[2];
     int rep[2] = {0, 0}, gmax[2] = {0, 0};
@@ -2113,89 +1981,55 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
-    unsigned *abort_dev_ptr = nullptr;       // device view of the host-mapped abort flag (in-kernel waits that time out)
-    HIP_TRY(hipHostGetDevicePointer((void **)&abort_dev_ptr, v->abort_host, 0));
+    unsigned *abort_dev_ptr = v->abort_dev;  // device view of the host-mapped status word (in-kernel waits that time out)
     // One resident, weight-stationary decoder per XCD (ar_xcd.hip): utterances dealt over the XCDs' decode slots, longest
     // first onto the slot that frees up first; a slot runs its utterances back to back (no replay boundaries here).
     v->last_was_xcd = false; v->last_was_xcm = false;
-    int nz = 0;                               // utterances that produce samples
-    for (int b = 0; b < B; ++b) nz += lens[Bp + b] > 0;
-    // auto: up to xcm_min (68) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
-    // against 3.4 / 4.7 M on the launch path), from there to xcm_max the matrix-core form through its 128 slots, above that the
-    // launch-per-step kernels
-    const int in_flight = v->n_slots > 0 && v->n_slots < nz ? v->n_slots : nz;
-    // the matrix-core form (16 slots per XCD) takes over from xcm_min utterances in flight; `xcd` = 0 turns both off, = 1 asks for
-    // the VALU form whatever the count
-    const bool xcm_wanted = v->xcd != 0 && (v->xcm == 1 || (v->xcm == -1 && v->xcd == -1 && in_flight > v->xcm_min && in_flight < v->xcm_max));
-    const bool xcd_wanted = xcm_wanted || v->xcd == 1 || (v->xcd == -1 && in_flight <= v->xcm_min);
-    if (xcd_wanted && !inputs && xd_supported(Hr, d.Hf, d.n_cls) && max_t > 0 && max_t < (1 << 24) && nz > 0) {
-        int xs = xcm_wanted ? v->xcm_slots : (v->xcd_slots < 1 ? 1 : v->xcd_slots);
-        if (v->n_slots > 0 && v->n_slots < xs) xs = v->n_slots;
-        if (nz < xs) xs = nz;
-        const int bxt = xcm_wanted ? XM_BX : xd_pick_bxt((xs + 7) / 8);
-        std::vector<long> xend(xs, 0);
-        std::vector<std::vector<XdSeg>> lists(xs);
-        for (int row : order) {
-            const int len = lens[Bp + row];
-            if (len <= 0) continue;
-            int best = 0;
-            for (int q = 1; q < xs; ++q) if (xend[q] < xend[best]) best = q;
-            lists[best].push_back(XdSeg{row, (int)xend[best], len, utt[row]});
-            xend[best] += len;
-        }
-        size_t max_seg = 1;
-        for (auto &l : lists) max_seg = l.size() + 1 > max_seg ? l.size() + 1 : max_seg;
-        std::vector<XdSeg> tab((size_t)8 * bxt * max_seg, XdSeg{-1, 0, 0, 0u});
-        XdParams xp{};
-        long longest = 0;
-        for (int q = 0; q < xs; ++q) {
-            for (size_t i = 0; i < lists[q].size(); ++i) tab[(size_t)q * max_seg + i] = lists[q][i];
-            const int x = q % 8;
-            if (xend[q] + 1 > xp.n_steps[x]) xp.n_steps[x] = (int)xend[q] + 1;
-            longest = xend[q] > longest ? xend[q] : longest;
-        }
-        VQ_REQUIRE(bxt > 0 && longest < (1L << 24), "vocoder: per-XCD schedule out of range");
-        TRY(v->xd_segs.reserve(tab.size() * sizeof(XdSeg)));
-        TRY(v->xd_x.reserve(xcm_wanted ? xm_exchange_bytes() : xd_exchange_bytes(bxt)));
-        TRY(v->stage.upload(v->xd_segs.p, tab.data(), tab.size() * sizeof(XdSeg), s));
-        xp.w_hh = v->w_hh; xp.w_fc1 = v->w_fc1; xp.b_fc1 = v->b_fc1; xp.w_fc2 = v->w_fc2; xp.b_fc2 = v->b_fc2;
-        xp.Gemb = v->Gemb; xp.b_hh = v->b_hh; xp.Gcond = v->gcond.as<float>(); xp.mulaw_tab = v->mulaw_tab;
-        xp.segs = v->xd_segs.as<XdSeg>(); xp.xg = v->xd_x.as<unsigned long long>(); xp.status = abort_dev_ptr;
-        xp.wav = wav; xp.mulaw = mulaw; xp.seed = seed; xp.max_seg = (int)max_seg; xp.n_slots = xs; xp.bxt = bxt;
-        xp.Lout = Lout; xp.F = T2; xp.upsample = d.upsample_t; xp.agent_stores = v->xcd_agent_stores;
-        xp.timeout_ticks = (unsigned)v->xcd_timeout_ms * 100000u; xp.dbg_drop_step = v->xcd_debug_drop_step;
-        xp.dbg_misplace = v->xcd_debug_misplace;
-        HIP_TRY(hipEventRecord(v->ev0, s));
-        TRY(xcm_wanted ? xm_launch(xp, s) : xd_launch(xp, s));
-        HIP_TRY(hipEventRecord(v->ev1, s));
-        v->last_steps = (int)longest;
-        v->have_last = false;
-        v->persist_pending = true;
-        v->last_was_xcd = !xcm_wanted; v->last_was_xcm = xcm_wanted;
-        return VQCPC_OK;
+    DecodePlan pl;
+    {
+        const PlanOpts po{v->xcd, v->xcm, v->xcm_min, v->xcm_max, v->xcd_slots, v->xcm_slots, v->n_slots,
+                          !inputs && xd_supported(Hr, d.Hf, d.n_cls) && max_t > 0};
+        VQ_REQUIRE(plan_decode(po, lens.data() + Bp, utt.data(), order, pl), "vocoder: a decode slot's schedule does not fit the resident "
+                   "decoders (< 2^24 - 1 samples); use more slots or xcd = -1");
     }
-    // BASELINE configs[2]: one utterance -> the persistent decoder (weights resident in registers, in-kernel exchanges)
-    if (v->persistent != 0 && B == 1 && !inputs && Hr == 896 && d.Hf == 256 && d.n_cls == 256 && lens[Bp] > 0 &&
-        lens[Bp] < (1 << 24)) {
-        const size_t ngr = (size_t)3 * PS_NB * PS_PAD;       // h_t, a_t, candidates: one 128-B line per workgroup each
-        TRY(v->px.reserve(ngr * sizeof(u64)));
-        HIP_TRY(hipMemsetAsync(v->px.p, 0, ngr * sizeof(u64), s));
-        unsigned *abort_dev = abort_dev_ptr;
-        PersistP pp{};
-        pp.w_hh = v->w_hh; pp.w_fc1 = v->w_fc1; pp.b_fc1 = v->b_fc1; pp.w_fc2 = v->w_fc2; pp.b_fc2 = v->b_fc2;
-        pp.Gemb4 = v->Gemb4; pp.bh4 = v->bh4; pp.Gcond = v->gcond.as<float>(); pp.mulaw_tab = v->mulaw_tab;
-        pp.gh = v->px.as<u64>(); pp.ga = pp.gh + PS_NB * PS_PAD; pp.gc = pp.ga + PS_NB * PS_PAD;
-        pp.abort_flag = abort_dev;
-        pp.wav = wav; pp.mulaw = mulaw; pp.n_steps = lens[Bp]; pp.upsample = d.upsample_t; pp.F = T2;
-        pp.utt = utt[0]; pp.seed = seed;
-        HIP_TRY(hipEventRecord(v->ev0, s));
-        hipLaunchKernelGGL((ar_persist_kernel<14>), dim3(PS_NB), dim3(512), 0, s, pp);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(v->ev1, s));
-        v->last_steps = lens[Bp];
-        v->have_last = false;              // no launch-per-step state to time
-        v->persist_pending = true;
-        return VQCPC_OK;
+    if (pl.path != 0) {
+        {
+            const bool xcm_wanted = pl.path == 3;
+            const int xs = pl.xs, bxt = pl.bxt;
+            const long longest = pl.longest;
+            auto &lists = pl.lists;
+            auto &xend = pl.xend;
+            size_t max_seg = 1;
+            for (auto &l : lists) max_seg = l.size() + 1 > max_seg ? l.size() + 1 : max_seg;
+            std::vector<XdSeg> tab((size_t)8 * bxt * max_seg, XdSeg{-1, 0, 0, 0u});
+            XdParams xp{};
+            for (int q = 0; q < xs; ++q) {
+                for (size_t i = 0; i < lists[q].size(); ++i) tab[(size_t)q * max_seg + i] = lists[q][i];
+                const int x = q % 8;
+                if (xend[q] + 1 > xp.n_steps[x]) xp.n_steps[x] = (int)xend[q] + 1;
+            }
+            TRY(v->xd_segs.reserve(tab.size() * sizeof(XdSeg)));
+            TRY(v->xd_x.reserve(xcm_wanted ? xm_exchange_bytes() : xd_exchange_bytes(bxt)));
+            TRY(v->stage.upload(v->xd_segs.p, tab.data(), tab.size() * sizeof(XdSeg), s));
+            xp.w_hh = v->w_hh; xp.w_fc1 = v->w_fc1; xp.b_fc1 = v->b_fc1; xp.w_fc2 = v->w_fc2; xp.b_fc2 = v->b_fc2;
+            xp.Gemb = v->Gemb; xp.b_hh = v->b_hh; xp.Gcond = v->gcond.as<float>(); xp.mulaw_tab = v->mulaw_tab;
+            xp.segs = v->xd_segs.as<XdSeg>(); xp.xg = v->xd_x.as<unsigned long long>(); xp.status = abort_dev_ptr;
+            xp.status_tag = v->epoch << 8;
+            xp.wav = wav; xp.mulaw = mulaw; xp.seed = seed; xp.max_seg = (int)max_seg; xp.n_slots = xs; xp.bxt = bxt;
+            xp.Lout = Lout; xp.F = T2; xp.upsample = d.upsample_t; xp.agent_stores = v->xcd_agent_stores;
+            xp.timeout_ticks = (unsigned)v->xcd_timeout_ms * 100000u; xp.dbg_drop_step = v->xcd_debug_drop_step;
+            xp.dbg_misplace = v->xcd_debug_misplace;
+            v->xcd_debug_misplace = 0;                     // one shot: the repeated call finds the workgroups where they are
+            HIP_TRY(hipEventRecord(v->ev0, s));
+            TRY(xcm_wanted ? xm_launch(xp, s) : xd_launch(xp, s));
+            HIP_TRY(hipEventRecord(v->ev1, s));
+            v->last_steps = (int)longest;
+            v->last_slots = xs;
+            v->have_last = false;
+            v->persist_pending = true;
+            v->last_was_xcd = !xcm_wanted; v->last_was_xcm = xcm_wanted;
+            return VQCPC_OK;
+        }
     }
 
     ArCall calls[2];
@@ -2312,6 +2146,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     }
     HIP_TRY(hipEventRecord(v->ev1, s));
     v->last_steps = max_t;
+    v->last_slots = n_slots;
     v->last_call = calls[0]; v->last_model = models[0]; v->have_last = true;
     if (models[0].fused) v->persist_pending = true;      // an in-kernel candidate wait may report a timeout
     return VQCPC_OK;
@@ -2385,7 +2220,8 @@ extern "C" int vqcpc_vocoder_glue(vqcpc_vocoder *v, const int64_t *idx, const in
     const auto &d = v->d;
     const size_t ng = (size_t)B * 2 * Tc * (d.dz + d.ds);
     hipLaunchKernelGGL(glue_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, speaker, v->code_emb,
-                       v->spk_emb, series, B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers);
+                       v->spk_emb, series, B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers, v->abort_dev, v->epoch << 8);
+    v->persist_pending = true;
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
 }

@@ -51,19 +51,11 @@ def make_buckets(lengths: Sequence[int], modes: Sequence[int], max_batch: int, m
 
 
 def generate_checked(vocoder: Vocoder, idx, spk, **kw):
-    """``Vocoder.generate`` followed by ``Vocoder.check()`` (one stream synchronisation): if an in-kernel hand-off of the
-    call timed out, the handle has fallen back to the launch-per-step kernels and the call is repeated ONCE -- same
-    sampling streams, so the same samples the fast path would have produced (``convert.py:75-83`` writes the waveform
-    right after ``generate``; nothing incomplete may reach it)."""
-    wav = vocoder.generate(idx, spk, **kw)
-    try:
-        vocoder.check()
-    except RuntimeError as e:
-        import warnings
-        warnings.warn(f"decode repeated on the fallback path: {e}")
-        wav = vocoder.generate(idx, spk, **kw)
-        vocoder.check()
-    return wav
+    """``Vocoder.generate`` with its default check: one stream synchronisation, the handle's status word read, and the call
+    repeated ONCE if an in-kernel hand-off of the resident decoders gave up (``convert.py:75-83`` writes the waveform right
+    after ``generate``; nothing incomplete may reach it).  Kept as a name for the callers that must not pass ``async_``."""
+    kw.pop("async_", None)
+    return vocoder.generate(idx, spk, **kw)
 
 
 def _pad_stack(mels: Sequence[torch.Tensor], ids: Sequence[int], device) -> torch.Tensor:

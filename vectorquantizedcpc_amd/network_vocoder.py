@@ -169,13 +169,20 @@ class Vocoder(nn.Module):
         self.__dict__.setdefault("_options", {})[name] = int(value)
 
     def check(self):
-        """Synchronise the current stream and raise ``RuntimeError`` if an in-kernel hand-off of the last ``generate``
-        timed out (``vqcpc_vocoder_check``): that call's waveform is incomplete, the handle has fallen back to one launch
-        per kernel and step, and repeating the call gives the samples the fast path would have produced."""
+        """Synchronise the current stream and raise if a call since the last check went wrong in a way only the device
+        knows (``vqcpc_vocoder_check``): ``IndexError`` for a code index or speaker id outside its embedding table (what
+        ``nn.Embedding`` raises at ``network_vocoder.py:73,75``), ``RuntimeError`` if an in-kernel hand-off timed out or the
+        resident decoders' workgroups were not dealt 32 per XCD -- that call's waveform is incomplete (or was not written),
+        and repeating the call gives the samples the fast path would have produced."""
         if self._handle is None:
             return
         torch.cuda.current_stream().synchronize()
-        _lib.check(_lib.load().vqcpc_vocoder_check(self._handle))
+        rc = _lib.load().vqcpc_vocoder_check(self._handle)
+        if rc != 0:
+            msg = _lib.load().vqcpc_last_error().decode()
+            if "index out of range in self" in msg:
+                raise IndexError("index out of range in self")
+            raise RuntimeError(f"libvqcpc_hip: {msg} (status {rc})")
 
     def last_timing(self):
         """(milliseconds, samples) of the last decode loop, from HIP events on its stream."""
@@ -185,9 +192,21 @@ class Vocoder(nn.Module):
         return ms.value, n.value
 
     def last_path(self) -> int:
-        """Decode loop of the last call: 0 launch-per-step kernels, 1 the 64-workgroup persistent decoder, 2 the per-XCD
-        resident decoders, 3 their matrix-core form (``vqcpc_vocoder_last_path``)."""
+        """Decode loop of the last call (``vqcpc_vocoder_last_path``): 2 the per-XCD resident decoders (up to 68 utterances in
+        flight), 3 their matrix-core form (69 .. 511), 0 the launch-per-step kernels -- which also take every call whose
+        dimensions are not the reference's (size_h_rnn 896, size_h_fc 256, 8-bit mu-law: ``config.py:69,76-77``), at about
+        half the speed; 1 = nothing has run yet."""
         return int(_lib.load().vqcpc_vocoder_last_path(self._native()))
+
+    def last_slots(self) -> int:
+        """Decode slots the last call's loop ran through (``vqcpc_vocoder_last_slots``)."""
+        return int(_lib.load().vqcpc_vocoder_last_slots(self._native()))
+
+    def workspace_bytes(self) -> int:
+        """Device bytes of the native handle's grow-only work buffers (conditioning rows, schedules, exchange areas)."""
+        n = C.c_uint64()
+        _lib.check(_lib.load().vqcpc_vocoder_workspace_bytes(self._native(), C.byref(n)))
+        return int(n.value)
 
     def kernel_times(self, reps: int = 1000):
         """(us GRU step, us fc1, us fc2 + draw, decode slots per launch, GRU kernel kind): ``vqcpc_vocoder_kernel_times``."""
@@ -205,15 +224,14 @@ class Vocoder(nn.Module):
             raise RuntimeError("z and speaker must be integer tensors (nn.Embedding indices, network_vocoder.py:73,75)")
         z = z.detach().to(torch.int64).contiguous()
         speaker = speaker.detach().to(device=z.device, dtype=torch.int64).contiguous()
-        # nn.Embedding raises on an out-of-range index (network_vocoder.py:73,75); so do we (ONE small read-back)
-        zlo, zhi, slo, shi = torch.stack((z.min(), z.max(), speaker.min(), speaker.max())).tolist()
-        if min(zlo, slo) < 0 or zhi >= self.conf.size_i_codebook or shi >= self.conf.n_speakers:
-            raise IndexError("index out of range in self")
+        # nn.Embedding raises on an out-of-range index (network_vocoder.py:73,75).  The glue kernel checks every index it reads
+        # and reports through the handle's status word, which check() turns into the same IndexError: no reduce kernels and
+        # no device synchronisation here (round 3 read min / max back on every call).
         return z, speaker
 
     @torch.no_grad()
     def generate(self, z: Tensor, speaker: Tensor, *, n_codes=None, seed=None, utt_base=None, utt_ids=None,
-                 return_mulaw: bool = False, max_steps: int = 0):
+                 return_mulaw: bool = False, max_steps: int = 0, async_: bool = False):
         """``network_vocoder.py:69-78``: waveform (B, 2*upsampling_t*T') from code indices and speaker ids.
 
         Keyword extras (not in the reference): ``n_codes`` per-utterance valid code counts of a
@@ -221,7 +239,29 @@ class Vocoder(nn.Module):
         seed and the number of utterances this module has generated so far; ``utt_ids`` gives every
         row its own stream id, so results do not depend on batching); ``return_mulaw`` also returns
         the int64 mu-law classes.
+
+        The reference's caller takes the result to the host right away (``convert.py:77-83``), so by default this call
+        synchronises its stream once and checks the handle's status word (``check()``): an index outside its table raises
+        ``IndexError`` like ``nn.Embedding``; if an in-kernel hand-off of the resident decoders gave up (a shared GPU), the
+        call is repeated ONCE -- same sampling streams, so the same samples -- with a warning.  ``async_=True`` only enqueues
+        the work (no synchronisation: pipelined callers); such callers call ``check()`` themselves before they use the
+        waveform.
         """
+        if not async_:
+            kw = dict(n_codes=n_codes, seed=seed, utt_base=utt_base, utt_ids=utt_ids, return_mulaw=return_mulaw, max_steps=max_steps)
+            if utt_base is None:
+                kw["utt_base"] = self._utterances_done             # a repeat must draw from the same streams
+            out = self.generate(z, speaker, async_=True, **kw)
+            try:
+                self.check()
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"Vocoder.generate: decode repeated ({e})")
+                out = self.generate(z, speaker, async_=True, **kw)
+                self.check()
+            if utt_base is None and utt_ids is None:
+                self._utterances_done += int(z.size(0))
+            return out
         z, speaker = self._prep(z, speaker)
         B, Tc = z.shape
         h = self._native()

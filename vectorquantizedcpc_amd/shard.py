@@ -32,7 +32,7 @@ def partition_contiguous(n: int, world_size: int) -> List[List[int]]:
 
 
 def gather_waveforms(wav: torch.Tensor, ids: Sequence[int], lengths: Sequence[int], n_total: int,
-                     dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+                     dst: int = 0, group=None, force_collective: bool = False) -> Optional[List[torch.Tensor]]:
     """Collect per-rank waveforms on ``dst``.
 
     wav: (n_local, L_local) this rank's padded waveforms, row k belongs to utterance ids[k] and
@@ -40,8 +40,10 @@ def gather_waveforms(wav: torch.Tensor, ids: Sequence[int], lengths: Sequence[in
     utterance order.  Message plan: one all_gather of (count, L) per rank, then one gather of the
     max-padded (count_max, L_max) float32 blocks and one of their (count_max, 2) int64 side tables
     (utterance id, length) -- integers travel as integers (a float32 column is exact only below 2**24).
+    A world of one rank needs no exchange and takes none, unless ``force_collective`` asks for the three collectives anyway
+    (``bench.py --workload manifest --force-gather`` on a 1-GPU box: the ragged RCCL path executes before an 8-GPU node does).
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return [wav[ids.index(i), : lengths[ids.index(i)]] for i in range(n_total)] if len(ids) == n_total else None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = wav.device
@@ -75,17 +77,27 @@ def gather_waveforms(wav: torch.Tensor, ids: Sequence[int], lengths: Sequence[in
 def convert_sharded(mels: Sequence[torch.Tensor], speakers: Sequence[int],
                     decode_fn: Callable[[List[int], List[torch.Tensor], List[int]], torch.Tensor],
                     samples_per_frame: int = 160, group=None, dst: int = 0,
-                    check_fn: Optional[Callable[[], None]] = None):
+                    check_fn: Optional[Callable[[], None]] = None, force_collective: bool = False,
+                    stats: Optional[dict] = None):
     """Batched ``convert.py:52-77`` over a node: LPT-shard, decode locally, gather on ``dst``.
 
     decode_fn(ids, mels, speakers) -> (n_local, L) padded waveforms for this rank's utterances
     (the HIP path: ``Encoder.encode_indices`` + ``Vocoder.generate``).  ``check_fn`` (``Vocoder.check``) runs between
     the local decode and the gather; on failure the local decode is repeated once on the fallback path.
+    ``stats`` (a dict) receives this rank's utterance count, sample count, local decode seconds and gather seconds (both
+    bracketed by a device synchronisation when the waveforms live on a GPU).
     """
+    import time
+
+    def sync():
+        if wav is not None and wav.is_cuda:
+            torch.cuda.synchronize(wav.device)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lengths = [int(m.shape[-1]) // 2 * 2 * samples_per_frame for m in mels]
     mine = partition_lpt(lengths, world)[rank]
+    wav = None
+    t0 = time.perf_counter()
     wav = decode_fn(mine, [mels[i] for i in mine], [speakers[i] for i in mine])
     if check_fn is not None:             # e.g. Vocoder.check: an aborted in-kernel hand-off must not reach the gather
         try:
@@ -93,4 +105,11 @@ def convert_sharded(mels: Sequence[torch.Tensor], speakers: Sequence[int],
         except RuntimeError:
             wav = decode_fn(mine, [mels[i] for i in mine], [speakers[i] for i in mine])     # the handle has fallen back
             check_fn()
-    return gather_waveforms(wav, mine, [lengths[i] for i in mine], len(mels), dst=dst, group=group)
+    sync()
+    t1 = time.perf_counter()
+    out = gather_waveforms(wav, mine, [lengths[i] for i in mine], len(mels), dst=dst, group=group, force_collective=force_collective)
+    sync()
+    if stats is not None:
+        stats.update({"utterances": len(mine), "samples": int(sum(lengths[i] for i in mine)), "decode_s": t1 - t0,
+                      "gather_s": time.perf_counter() - t1})
+    return out
