@@ -117,3 +117,73 @@ def test_cli_encode_and_convert_end_to_end(tmp_path):
     # convert.py:57,79-80: the output is re-normalised to the input's integrated loudness
     from oracle import loudness_ref
     assert abs(loudness_ref.integrated_loudness(w3, 16000) - loudness_ref.integrated_loudness(tone, 16000)) < 1e-4
+
+
+def test_ragged_conditioning_allocates_the_utterances_own_frames_and_chunked_decodes_agree():
+    """the conditioning rows (Gcond, 3 x 896 fp32 per frame) are computed for every utterance's own frames, not
+    for B x T_max; and a decode cut into several calls by the driver's memory budget gives the same waveforms as one call."""
+    enc, voc = models()
+    n_codes = [60] + [3] * 7                                                   # 120 + 7 x 6 = 162 frames of 8 x 120 = 960
+    z = synth.randint("rag/z", (8, 60), 512).cuda()
+    spk = synth.randint("rag/s", (8,), 102).cuda()
+    wav = voc.generate(z, spk, n_codes=n_codes, seed=13, utt_ids=list(range(8)))
+    ws = voc.workspace_bytes()
+    own, padded = 162 * 3 * 896 * 4, 960 * 3 * 896 * 4
+    assert own <= ws < padded, (own, ws, padded)                              # the padded Gcond alone would be 10.3 MB
+    for i in (0, 3, 7):                                                        # ... and every utterance still equals itself decoded alone
+        one = voc.generate(z[i:i + 1, : n_codes[i]], spk[i:i + 1], seed=13, utt_ids=[i])
+        assert torch.equal(wav[i, : 320 * n_codes[i]], one[0]), i
+        assert not bool(wav[i, 320 * n_codes[i]:].any())
+    # the driver's chunked continuous batching (a budget that cuts 12 utterances into several calls) == one call
+    Ts = [40, 12, 30, 8, 22, 36, 10, 18, 26, 14, 34, 20]
+    mels = [synth.mel(f"rag/m{i}", 1, t)[0] for i, t in enumerate(Ts)]
+    sp = [i % 102 for i in range(12)]
+    whole = driver.convert_utterances(enc, voc, mels, sp, seed=13, slots=4)
+    budget = 3 * (40 * driver.BYTES_PER_OWN_FRAME + 40 * (driver.BYTES_PER_PADDED_FRAME + 4 * 160))
+    assert len(driver.decode_chunks([driver.out_frames(t) for t in Ts], budget)) >= 3
+    parts = driver.convert_utterances(enc, voc, mels, sp, seed=13, slots=4, mem_budget_bytes=budget)
+    assert all(torch.equal(a, b) for a, b in zip(whole, parts))
+
+
+def test_batched_wav_front_end_equals_per_utterance_calls(tmp_path):
+    """`cli convert`'s batched front end (driver.front_end_utterances: bucket by sample rate, resample with ceil lengths,
+    loudness and log-mel with `lengths=` on padded rows) on wavs of different lengths and rates (16 k and 22.05 k, mono float and
+    stereo int16) must give, per utterance, what the one-utterance calls give (io.load_wav + Meter + wave_to_mel), and
+    cli.convert_files the outputs of single-utterance runs."""
+    import numpy as np
+    from scipy.io import wavfile
+    from vectorquantizedcpc_amd import cli, io, loudness, preprocess
+    enc, voc = models()
+    specs = [(16000, 9000, 1, np.float32), (22050, 15000, 2, np.int16), (16000, 12345, 1, np.int16), (22050, 9876, 1, np.float32)]
+    paths = []
+    for i, (sr, n, ch, dt) in enumerate(specs):
+        t = np.arange(n) / sr
+        x = 0.3 * np.sin(2 * np.pi * (200 + 90 * i) * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 1.5 * t))
+        if ch == 2:
+            x = np.stack([x, 0.5 * x], axis=1)
+        data = (x * 20000).astype(np.int16) if dt == np.int16 else x.astype(np.float32)
+        p = tmp_path / f"in{i}.wav"
+        wavfile.write(str(p), sr, data)
+        paths.append(str(p)[:-4])
+    rates, waves = zip(*[io.read_wav_file(p + ".wav") for p in paths])
+    mels, lufs = driver.front_end_utterances(list(waves), list(rates), torch.device("cuda"))
+    meter = loudness.Meter(16000)
+    for i, p in enumerate(paths):
+        w1 = io.load_wav(p + ".wav", 16000)                                       # one utterance: read + resample at load
+        w1 = torch.as_tensor(w1, dtype=torch.float32, device="cuda")
+        l1 = float(meter.integrated_loudness(w1[None])[0])
+        m1 = preprocess.wave_to_mel(w1[None])[0]
+        assert mels[i].shape == m1.shape, (i, mels[i].shape, m1.shape)
+        assert torch.equal(mels[i], m1), i
+        assert abs(lufs[i] - l1) < 1e-9, (i, lufs[i], l1)
+    out_all = tmp_path / "all"
+    out_all.mkdir()
+    entries = [(p, 3 + i, f"o{i}") for i, p in enumerate(paths)]
+    cli.convert_files(enc, voc, entries, str(out_all), 13, slots=2)
+    for i in range(len(paths)):                        # the files equal one-utterance runs of convert.py:72-83 on the same sampling stream
+        idx = enc.encode_indices(m_i := mels[i][None])
+        one = voc.generate(idx, torch.tensor([3 + i], device="cuda"), seed=13, utt_ids=[i])
+        n = 320 * driver.out_frames(int(m_i.shape[-1]))
+        want = loudness.match_loudness([one[0, :n]], [lufs[i]])[0].cpu().numpy()
+        sr, got = wavfile.read(str(out_all / f"o{i}.wav"))
+        assert sr == 16000 and got.shape == want.shape and np.array_equal(got, want), i

@@ -48,3 +48,23 @@ def test_a_schedule_of_2_pow_24_samples_falls_through_in_auto_mode_and_is_an_err
         plan(three, slots=1, xcd=1)
     with pytest.raises(RuntimeError, match="does not fit the resident decoders"):
         plan(three, slots=1, xcm=1)
+
+
+def test_decode_chunks_respect_the_memory_budget_and_keep_every_utterance():
+    """driver.decode_chunks: the reference's 9 474-utterance set (README.md:125) as ONE decode call would want ~35 GB of conditioning
+    rows; the driver cuts the list into calls under a work-space budget."""
+    import random
+    from vectorquantizedcpc_amd import driver
+    rnd = random.Random(13)
+    n_codes = [rnd.randint(50, 500) for _ in range(9474)]                     # 1 .. 10 s
+    for budget in (1 << 30, 8 << 30):
+        chunks = driver.decode_chunks(n_codes, budget)
+        assert [i for c in chunks for i in c] == list(range(9474))             # in order, nothing lost
+        for c in chunks:
+            own = sum(2 * n_codes[i] for i in c)
+            t2 = max(2 * n_codes[i] for i in c)
+            need = own * driver.BYTES_PER_OWN_FRAME + len(c) * t2 * (driver.BYTES_PER_PADDED_FRAME + 4 * 160)
+            assert need <= budget or len(c) == 1
+        assert len(chunks) > 1
+    assert driver.decode_chunks([100, 100], 1) == [[0], [1]]                   # a budget below one utterance: one per call
+    assert driver.decode_chunks([100] * 32, 8 << 30) == [list(range(32))]      # the bench workload: one call

@@ -5,7 +5,7 @@
 
 Runs separate `rocprofv3 --pmc` passes (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum TCC_MISS_sum -- they do not fit one pass,
 MI355X_MICROARCH.md "rocprofv3 PMC slots") over a short decode of `--utterances` concurrent utterances and writes
-profiles/r02_pmc_traffic.json: per-launch averages of the GRU-step kernel, the gfx950 FETCH_SIZE x2 correction
+profiles/r04_pmc_traffic.json: per-launch averages of the GRU-step kernel, the gfx950 FETCH_SIZE x2 correction
 (MI355X_MICROARCH.md "HBM"), and `kernel_source_sha` = the hash bench.py checks before it reports `roofline.traffic`
 (a file measured on other kernel sources is refused there).
 
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--codes", type=int, default=0, help="codes per utterance (default: 25 = 8 000 samples for xcd, 1 = 320 samples = plenty of launches otherwise)")
     ap.add_argument("--mode", default="xcd")
     ap.add_argument("--target", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
     args = ap.parse_args()
     if args.codes <= 0:
         args.codes = 25 if args.mode in ("xcd", "xcm") else 1

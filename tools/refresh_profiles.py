@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerate the measured artifacts under profiles/ for the current sources, on the MI355X box, in one go:
 
-    python3 tools/refresh_profiles.py [--round r03] [--skip name,...]
+    python3 tools/refresh_profiles.py [--round r04] [--skip name,...] [--only name,...]
 
   bench        python bench.py --steps 20 --warmup 5                       -> <round>_bench_n1.json
   trace        rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 (same arguments as the driver's run)
@@ -9,6 +9,10 @@
   pmc          tools/collect_traffic.py (per-XCD decoders, 32 utterances)  -> <round>_pmc_traffic.json
   pmc_big      tools/collect_traffic.py --utterances 128 --mode graph16    -> <round>_pmc_traffic_big128.json
   pmc_xcm      tools/collect_traffic.py --utterances 128 --mode xcm        -> <round>_pmc_traffic_xcm128.json
+  pmc_sq       tools/collect_sq.py --mode xcd (32 utterances), --mode xcm (128): SQ counters (wave / busy / wait cycles, VALU / MFMA /
+               LDS instructions, MFMA-busy cycles)                         -> <round>_pmc_sq_xcd32.json, <round>_pmc_sq_xcm128.json
+  manifest     python bench.py --workload manifest --force-gather (BASELINE configs[4] through shard.convert_sharded, the ragged
+               gather on RCCL at world size 1)                             -> <round>_bench_manifest_rccl_world1.json
   encoder      rocprofv3 --kernel-trace --stats -- python3 tools/profile_encoder.py [c1]
                                                                            -> <round>_encoder_c2_kernel_stats.csv, <round>_encoder_c1_kernel_stats.csv
   timeline     tools/xcd_timeline.py 1 8 32, tools/xcm_timeline.py 128 (debug build with stamps)
@@ -53,10 +57,14 @@ def kernel_stats(scratch):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r03")
+    ap.add_argument("--round", default="r04")
     ap.add_argument("--skip", default="")
+    ap.add_argument("--only", default="")
     args = ap.parse_args()
     skip = set(s for s in args.skip.split(",") if s)
+    if args.only:
+        every = {"bench", "trace", "pmc", "pmc_big", "pmc_xcm", "pmc_sq", "manifest", "encoder", "timeline", "probe", "by_batch", "summary"}
+        skip = every - set(s for s in args.only.split(",") if s)
     R = args.round
     # on the GPU box only gpurun_out/ travels back: the artifacts go to gpurun_out/profiles_<round>/ (copy them into profiles/
     # afterwards), the bulky scratch (kernel traces) to /tmp
@@ -91,6 +99,14 @@ def main():
     if "pmc_xcm" not in skip:
         ok["pmc_xcm"] = run([PY, "tools/collect_traffic.py", "--mode", "xcm", "--utterances", "128",
                              "--out", os.path.join(P, f"{R}_pmc_traffic_xcm128.json")], out=os.path.join(S, "pmc_xcm.log"))
+    if "pmc_sq" not in skip:
+        ok["pmc_sq_xcd"] = run([PY, "tools/collect_sq.py", "--mode", "xcd", "--utterances", "32", "--out", os.path.join(P, f"{R}_pmc_sq_xcd32.json")],
+                               out=os.path.join(S, "pmc_sq_xcd.log"), timeout=900)
+        ok["pmc_sq_xcm"] = run([PY, "tools/collect_sq.py", "--mode", "xcm", "--utterances", "128", "--out", os.path.join(P, f"{R}_pmc_sq_xcm128.json")],
+                               out=os.path.join(S, "pmc_sq_xcm.log"), timeout=900)
+    if "manifest" not in skip:
+        ok["manifest"] = run([PY, "bench.py", "--workload", "manifest", "--manifest", "512", "--force-gather", "--steps", "3", "--warmup", "1"],
+                             out=os.path.join(P, f"{R}_bench_manifest_rccl_world1.json"))
     if "encoder" not in skip:
         for case, extra in (("c2", []), ("c1", ["c1"])):
             d = os.path.join(S, "enc_" + case)
@@ -157,6 +173,26 @@ def summary(P, R):
                          f"algorithmic {t['algorithmic_bytes_per_launch'] / 1e6:.2f} MB, ratio {t['traffic_over_algorithmic']:.2f}, L2 hit rate {t['l2_hit_rate']:.3f}")
         except (OSError, ValueError, KeyError) as e:
             lines.append(f"* `{name}` missing: {e}")
+    for name in (f"{R}_pmc_sq_xcd32.json", f"{R}_pmc_sq_xcm128.json"):
+        try:
+            q = json.load(open(os.path.join(P, name)))
+            d = q["derived"]
+            lines.append(f"* `{name}`: {q['kernel'][:60]}, {q['utterances']} utterances x {q['sample_steps']} steps: "
+                         f"MFMA-busy / kernel clocks {d.get('mfma_busy_over_kernel_clocks', float('nan')):.3f} "
+                         f"({d.get('mfma_busy_clocks_per_simd_per_step', float('nan')):.0f} clocks per SIMD and step of {d.get('clocks_per_sample_step', float('nan')):.0f}), "
+                         f"per wave and step: {d.get('SQ_INSTS_VALU_per_wave_per_step', float('nan')):.0f} VALU, {d.get('SQ_INSTS_MFMA_per_wave_per_step', float('nan')):.0f} MFMA, "
+                         f"{d.get('SQ_INSTS_LDS_per_wave_per_step', float('nan')):.0f} LDS instructions; of the wave cycles: active {d.get('SQ_ACTIVE_INST_ANY_over_WAVE_CYCLES', float('nan')):.3f}, "
+                         f"waiting (s_waitcnt / barrier) {d.get('SQ_WAIT_ANY_over_WAVE_CYCLES', float('nan')):.3f}, issue-stalled {d.get('SQ_WAIT_INST_ANY_over_WAVE_CYCLES', float('nan')):.3f}; "
+                         f"{q.get('us_per_step_profiled')} us per step under the profiler")
+        except (OSError, ValueError, KeyError) as e:
+            lines.append(f"* `{name}` missing: {e}")
+    try:
+        m = json.load(open(os.path.join(P, f"{R}_bench_manifest_rccl_world1.json")))
+        lines.append(f"* `{R}_bench_manifest_rccl_world1.json` (`python bench.py --workload manifest --force-gather`): {m['value']:.0f} samples/s, "
+                     f"{m['config']['utterances']} utterances, backend {m['backend']} x {m['rccl_ranks']}, ragged gather {m['gather']['ms_rank0_last_step']:.2f} ms, "
+                     f"all gathered: {m['all_utterances_gathered_with_their_lengths']}, work space {m.get('workspace_peak_bytes_rank0', 0) / 1e9:.2f} GB")
+    except (OSError, ValueError, KeyError) as e:
+        lines.append(f"* manifest (configs[4]) line missing: {e}")
     with open(os.path.join(P, f"{R}_summary.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
 

@@ -14,9 +14,10 @@ struct XdParams {
     const float *w_fc1, *b_fc1, *w_fc2, *b_fc2;     // (Hf, Hr), (n_cls, Hf) plain
     const float *Gemb;        // [n_cls][3Hr]   sample embedding . W_ih[:, :de]^T
     const float *b_hh;        // [3Hr]
-    const float *Gcond;       // [rows][F][3Hr] conditioning rows (W_ih[:, de:] cond + b_ih)
+    const float *Gcond;       // [sum of the utterances' frames][3Hr] conditioning rows (W_ih[:, de:] cond + b_ih), ragged: utterance `row`
+                              // starts at row gbase[row], gbase = (const int *)(segs + 8 * slots per XCD * max_seg): behind the table
     const float *mulaw_tab;   // [n_cls]
-    const XdSeg *segs;        // [8 * bxt slots][max_seg]; slot s lives on XCD s % 8 as its local slot s / 8
+    const XdSeg *segs;        // [8 * bxt slots][max_seg]; slot s lives on XCD s % 8 as its local slot s / 8; then int gbase[rows]
     unsigned long long *xg;   // exchange area (xd_exchange_bytes), zeroed by xd_launch
     unsigned *status;         // host-mapped word: status_tag | 1 = an exchange timed out, | 2 = the workgroups were not dealt 32 per XCD
     unsigned status_tag;      // the call's epoch << 8 (which call of the handle reported)

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         const XdSeg sg = (int)e < bx ? p.segs[(size_t)(xcc + 8 * e) * p.max_seg] : XdSeg{-1, 0, 0, 0u};
         seg_st[e * 8 + 0] = 0; seg_st[e * 8 + 1] = sg.len > 0 ? sg.row : -1; seg_st[e * 8 + 2] = sg.t0; seg_st[e * 8 + 3] = sg.len;
         seg_st[e * 8 + 4] = (int)sg.utt; seg_st[e * 8 + 5] = 0; seg_st[e * 8 + 6] = 0;      // samples into / index of the conditioning frame
+        seg_st[e * 8 + 7] = sg.len > 0 ? ((const int *)(p.segs + (size_t)8 * BXT * p.max_seg))[sg.row] : 0;      // the utterance's first Gcond row
         sinfo[e * 4 + 0] = 0; sinfo[e * 4 + 1] = 0; sinfo[e * 4 + 2] = 0;
     }
     __syncthreads();
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             st_active = false; st_first = false; st_emit = false;
             if (!cell_on) return;
             int si = seg_st[cb * 8 + 0], row = seg_st[cb * 8 + 1], t0 = seg_st[cb * 8 + 2], len = seg_st[cb * 8 + 3];
-            int fpos = seg_st[cb * 8 + 5], fidx = seg_st[cb * 8 + 6];
+            int fpos = seg_st[cb * 8 + 5], fidx = seg_st[cb * 8 + 6], gb = seg_st[cb * 8 + 7];
             unsigned utt = (unsigned)seg_st[cb * 8 + 4];
             int lt = tn - t0;
             if (row >= 0 && lt >= 1 && lt <= len) { st_emit = true; st_erow = row; st_eidx = lt - 1; }    // x_{tn-1} is sample lt - 1 of `row`
@@ -336,8 +337,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 row = sg.len > 0 ? sg.row : -1; t0 = sg.t0; len = sg.len; utt = sg.utt;
                 lt = tn - t0;
                 fpos = 0; fidx = 0;
+                gb = row >= 0 ? ((const int *)(p.segs + (size_t)8 * BXT * p.max_seg))[row] : 0;
                 if (cu == 0) { seg_st[cb * 8 + 0] = si; seg_st[cb * 8 + 1] = row; seg_st[cb * 8 + 2] = t0; seg_st[cb * 8 + 3] = len; seg_st[cb * 8 + 4] = (int)utt;
-                               seg_st[cb * 8 + 5] = 0; seg_st[cb * 8 + 6] = 0; }
+                               seg_st[cb * 8 + 5] = 0; seg_st[cb * 8 + 6] = 0; seg_st[cb * 8 + 7] = gb; }
             }
             st_active = row >= 0 && lt >= 0 && lt < len;
             st_first = lt == 0;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 if (fpos == p.upsample) { fpos = 0; fidx += 1; }
                 if (fpos == 0 && cu < UPB) {                         // next conditioning frame (once per hop)
                     const int f = fidx < p.F ? fidx : p.F - 1;
-                    const float *gcp = p.Gcond + ((size_t)row * p.F + f) * 3 * HR + UPB * rank + cu;
+                    const float *gcp = p.Gcond + ((size_t)gb + f) * 3 * HR + UPB * rank + cu;
                     g0 = gcp[0]; g1 = gcp[HR]; g2 = gcp[2 * HR];
                 }
                 fpos += 1;

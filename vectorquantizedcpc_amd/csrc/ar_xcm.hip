@@ -84,7 +84,7 @@ struct Lds {
     static constexpr int gcl = fcx + 4 * 8 * BX;         // [BX][84]  conditioning rows in use [gate][unit]
     static constexpr int noise = gcl + BX * 84;           // [2][BX][8]
     static constexpr int mtab = noise + 2 * BX * 8;       // [NC]
-    static constexpr int sinfo = mtab + NC;               // int [2][BX][8] {active, first, lt, utt, row, frame to load or -1}
+    static constexpr int sinfo = mtab + NC;               // int [2][BX][8] {active, first, lt, utt, row, frame to load or -1, the utterance's first Gcond row}
     static constexpr int xs = sinfo + 2 * BX * 8;         // int [BX]  x_t
     static constexpr int segst = xs + BX;                 // int [BX][8] {index, row, t0, len, utt, samples into / index of the conditioning frame}
     static constexpr int bqs = segst + BX * 8;            // [3][32] b_hh of the owned units, then b_fc1 [8], b_fc2 [8] of the owned rows
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         const XdSeg sg = (int)e < bx ? p.segs[(size_t)(xcc + 8 * e) * p.max_seg] : XdSeg{-1, 0, 0, 0u};
         int *st = segst + e * 8;
         st[0] = 0; st[1] = sg.len > 0 ? sg.row : -1; st[2] = sg.t0; st[3] = sg.len; st[4] = (int)sg.utt; st[5] = 0; st[6] = 0;
+        st[7] = sg.len > 0 ? ((const int *)(p.segs + (size_t)8 * BX * p.max_seg))[sg.row] : 0;      // the utterance's first Gcond row
     }
     __syncthreads();
 
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
     auto advance = [&](int tn, unsigned ln) {
         if (ln >= (unsigned)BX) return;
         int *st = segst + ln * 8;
-        int sg_i = st[0], sg_row = st[1], sg_t0 = st[2], sg_len = st[3], sg_fpos = st[5], sg_fidx = st[6];
+        int sg_i = st[0], sg_row = st[1], sg_t0 = st[2], sg_len = st[3], sg_fpos = st[5], sg_fidx = st[6], sg_gb = st[7];
         unsigned sg_utt = (unsigned)st[4];
         int lt = tn - sg_t0;
         if (sg_row >= 0 && lt >= sg_len) {                        // next utterance of this slot
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
             sg_row = sg.len > 0 ? sg.row : -1; sg_t0 = sg.t0; sg_len = sg.len; sg_utt = sg.utt;
             lt = tn - sg_t0;
             sg_fpos = 0; sg_fidx = 0;
-            st[0] = sg_i; st[1] = sg_row; st[2] = sg_t0; st[3] = sg_len; st[4] = (int)sg_utt;
+            sg_gb = sg_row >= 0 ? (PAR_GLOBAL(const int, par, PAR_SEGS) + 4 * ((size_t)8 * BX * max_seg))[sg_row] : 0;
+            st[0] = sg_i; st[1] = sg_row; st[2] = sg_t0; st[3] = sg_len; st[4] = (int)sg_utt; st[7] = sg_gb;
         }
         const bool active = sg_row >= 0 && lt >= 0 && lt < sg_len;
         int frame = -1;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         }
         st[5] = sg_fpos; st[6] = sg_fidx;
         int *si = sinfo + ((tn & 1) * BX + (int)ln) * 8;
-        si[0] = active ? 1 : 0; si[1] = lt == 0 ? 1 : 0; si[2] = lt; si[3] = (int)sg_utt; si[4] = sg_row; si[5] = frame;
+        si[0] = active ? 1 : 0; si[1] = lt == 0 ? 1 : 0; si[2] = lt; si[3] = (int)sg_utt; si[4] = sg_row; si[5] = frame; si[6] = sg_gb;
     };
     // conditioning rows of the slots that enter a new frame at step tn, and the Gumbel noise of that step's draw (wave BOOK)
     auto prepare = [&](int tn, unsigned ln) {
@@ -301,10 +303,10 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
         while (fresh) {
             const int b = __ffsll((long long)fresh) - 1;
             fresh &= fresh - 1;
-            const int f = sn[b * 8 + 5], row = sn[b * 8 + 4];
+            const int f = sn[b * 8 + 5], gb = sn[b * 8 + 6];
             for (unsigned e = ln; e < 84; e += 64) {
                 const unsigned g = e / UPB, u = e - g * UPB;
-                gcl[b * 84 + e] = PAR_GLOBAL(const float, par, PAR_GCOND)[((size_t)row * par_i(par, PAR_F) + f) * 3 * HR + g * HR + UPB * rank + u];
+                gcl[b * 84 + e] = PAR_GLOBAL(const float, par, PAR_GCOND)[((size_t)gb + f) * 3 * HR + g * HR + UPB * rank + u];
             }
         }
 #pragma unroll

@@ -322,7 +322,8 @@ int vq_lstm_run(LstmPlan *p, const float *x, int B, int T, float *out, hipStream
 struct ArSlot { int row, t0, len; unsigned utt; };
 
 struct ArCall {
-    const float *Gcond;        // [Bpad][F][3Hr] = W_ih[:, de:] cond + b_ih
+    const float *Gcond;        // [sum of the utterances' frames][3Hr] = W_ih[:, de:] cond + b_ih, ragged: utterance `row` starts at row gbase[row]
+    const int *gbase;          // [B] first Gcond row of every utterance (prefix sums of the conditioning frame counts)
     const int64_t *inputs;     // teacher forcing (B, Ts) or null
     float *wav;                // (B, Lout) or null
     int64_t *mulaw;            // (B, Lout) or null
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(64 * (4 + NB)) void ar_gru_kernel(ArModel m, const 
                 const float4 eq = m.Gemb4[((size_t)x * (Hr >> 2) + rg) * 4 + u];
                 ge0 = eq.x; ge1 = eq.y; ge2 = eq.z;
                 if (!m.gc_replay) {
-                    const float *gc = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
+                    const float *gc = c.Gcond + ((size_t)c.gbase[sl.row] + lt / m.upsample) * 3 * Hr + unit;
                     gc0 = gc[0]; gc1 = gc[Hr]; gc2 = gc[2 * Hr];
                 }
                 hold = first ? 0.f : hprev;                     // a new utterance starts from h = 0
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(1024) void ar_gru_big_kernel(ArModel m, const ArCal
                 const float4 eq = m.Gemb4[((size_t)x * (Hr >> 2) + rgq) * 4 + u];
                 ge[p][0] = eq.x; ge[p][1] = eq.y; ge[p][2] = eq.z;
                 if (!m.gc_replay) {
-                    const float *pg = c.Gcond + ((size_t)sl.row * c.F + lt / m.upsample) * 3 * Hr + unit;
+                    const float *pg = c.Gcond + ((size_t)c.gbase[sl.row] + lt / m.upsample) * 3 * Hr + unit;
                     gc[p][0] = pg[0]; gc[p][1] = pg[Hr]; gc[p][2] = pg[2 * Hr];
                 }
                 hold[p] = first ? 0.f : hprev[p];
@@ -1187,7 +1188,7 @@ __global__ __launch_bounds__(256) void ar_next_row_kernel(ArModel m, const ArCal
     if (!m.gc_replay || sl.row < 0 || c.t_base < sl.t0) return;
     const int f = (c.t_base - sl.t0) / m.upsample;
     if (f >= c.F) return;
-    const float *src = c.Gcond + ((size_t)sl.row * c.F + f) * 3 * m.Hr;
+    const float *src = c.Gcond + ((size_t)c.gbase[sl.row] + f) * 3 * m.Hr;
     for (int rg = threadIdx.x; rg < (m.Hr >> 2); rg += 256) {           // [3][Hr] row -> unit quads of row group rg
         const float4 r4 = *(const float4 *)(src + 4 * rg), z4 = *(const float4 *)(src + m.Hr + 4 * rg),
                      n4 = *(const float4 *)(src + 2 * m.Hr + 4 * rg);
@@ -1340,7 +1341,7 @@ struct vqcpc_vocoder {
     int two_groups = 1;                  // 0 = always one group
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf series, gi, out0, cond, gcond, hseq, len;
+    DevBuf series, gi, out0, cond, condc, gcond, gbase, hseq, len;
     DevBuf hall, a1c;                    // teacher-forced scan: h_t and fc1 outputs of one chunk
     unsigned *abort_host = nullptr;      // the handle's status word: pinned host memory the kernels write and the host reads without a HIP call
     unsigned *abort_dev = nullptr;       // the device's view of it
@@ -1415,7 +1416,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->w_hh) (void)hipFree(v->w_hh);
     if (v->Gemb4) (void)hipFree(v->Gemb4);
     if (v->bh4) (void)hipFree(v->bh4);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->condc, &v->gcond, &v->gbase, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -1683,7 +1684,7 @@ extern "C" int vqcpc_vocoder_last_slots(vqcpc_vocoder *v) {
 extern "C" int vqcpc_vocoder_workspace_bytes(vqcpc_vocoder *v, uint64_t *bytes) {
     VQ_REQUIRE(v && bytes, "vqcpc_vocoder_workspace_bytes: null argument");
     uint64_t n = 0;
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->condc, &v->gcond, &v->gbase, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
     for (DevBuf *b : bufs) n += b->cap;
     for (auto &G : v->grp) { DevBuf *gb[] = {&G.har, &G.a1, &G.cand_s, &G.cand_k, &G.gcur, &G.candg, &G.slot_tab, &G.cur}; for (DevBuf *b : gb) n += b->cap; }
     *bytes = n;
@@ -1696,6 +1697,18 @@ extern "C" int vqcpc_vocoder_last_timing(vqcpc_vocoder *v, float *loop_ms, int *
     HIP_TRY(hipEventElapsedTime(loop_ms, v->ev0, v->ev1));
     *n_steps = v->last_steps;
     return VQCPC_OK;
+}
+
+// Conditioning rows of the utterances' OWN frames only: cond (B, T2, dl) padded -> condc (sum of frames, dl), utterance b's frames
+// at rows gbase[b] .. gbase[b] + frames[b] - 1.  The Gcond GEMM then runs over those rows alone: on a ragged manifest (mean 3.4 s
+// of a 10 s maximum) two thirds of B x T_max are padding -- 5.5 GB of Gcond and the GEMM behind it for 1.9 GB of use.
+__global__ void compact_rows_kernel(const float4 *__restrict__ cond, float4 *__restrict__ condc, const int *__restrict__ frames,
+                                    const int *__restrict__ gbase, int T2, int dl4) {
+    const int b = blockIdx.y, f = blockIdx.x;
+    if (f >= frames[b]) return;
+    const float4 *src = cond + ((size_t)b * T2 + f) * dl4;
+    float4 *dst = condc + ((size_t)gbase[b] + f) * dl4;
+    for (int c = threadIdx.x; c < dl4; c += blockDim.x) dst[c] = src[c];
 }
 
 // conditioning: glue -> 2-layer bi-GRU prenet -> cond (B, 2Tc, 2Hp); lens_dev = valid frames per utterance
@@ -1965,7 +1978,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // upload through the pinned arena: no synchronisation of the caller's stream
     TRY(v->stage.begin(lens.size() * sizeof(int) + (table[0].size() + table[1].size()) * sizeof(ArSlot) +
                        (size_t)(tiles[0] + tiles[1]) * 16 * sizeof(ArSlot) + 2 * sizeof(ArCall) + 256 +
-                       (size_t)8 * XM_BX * (B + 1) * sizeof(XdSeg)));
+                       (size_t)8 * XM_BX * (B + 1) * sizeof(XdSeg) + (size_t)2 * (B + 16) * sizeof(int)));
     TRY(v->stage.upload(v->len.p, lens.data(), lens.size() * sizeof(int), s));
     for (int g = 0; g < n_grp; ++g) {
         TRY(v->stage.upload(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), s));
@@ -1973,11 +1986,27 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     }
     const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
 
+    // Gcond over every utterance's own frames (ragged): row base of utterance b = prefix sum of the frame counts
+    std::vector<int> gbase(B);
+    long grows = 0;
+    for (int b = 0; b < B; ++b) { gbase[b] = (int)grows; grows += lens[b]; }
+    VQ_REQUIRE(grows < (1L << 31), "vocoder: %ld conditioning frames in one call", grows);
+    TRY(v->gbase.reserve((size_t)B * sizeof(int)));
+    TRY(v->stage.upload(v->gbase.p, gbase.data(), (size_t)B * sizeof(int), s));
     const size_t rows = (size_t)B * T2;
     TRY(v->cond.reserve(rows * dl * sizeof(float)));
     TRY(run_condition(v, idx, spk, B, Tc, frames_dev, v->cond.as<float>(), s));
-    TRY(v->gcond.reserve(rows * 3 * Hr * sizeof(float)));
-    TRY(vq_gemm_chain(v->cond.as<float>(), dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)rows, 3 * Hr, dl, dl, s));
+    const size_t crows = grows > 0 ? (size_t)grows : 1;
+    TRY(v->gcond.reserve(crows * 3 * Hr * sizeof(float)));
+    const float *cond_rows = v->cond.as<float>();
+    if (ragged) {
+        TRY(v->condc.reserve(crows * dl * sizeof(float)));
+        hipLaunchKernelGGL(compact_rows_kernel, dim3(T2, B), dim3(64), 0, s, (const float4 *)v->cond.p, (float4 *)v->condc.p, v->len.as<int>(),
+                           v->gbase.as<int>(), T2, dl / 4);
+        cond_rows = v->condc.as<float>();
+    }
+    if (grows > 0)
+        TRY(vq_gemm_chain(cond_rows, dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)grows, 3 * Hr, dl, dl, s));
     if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
@@ -2008,7 +2037,10 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
                 const int x = q % 8;
                 if (xend[q] + 1 > xp.n_steps[x]) xp.n_steps[x] = (int)xend[q] + 1;
             }
-            TRY(v->xd_segs.reserve(tab.size() * sizeof(XdSeg)));
+            // behind the table: first Gcond row of every utterance (the kernels find it from the table's own address)
+            const size_t tab_bytes = tab.size() * sizeof(XdSeg);
+            TRY(v->xd_segs.reserve(tab_bytes + (size_t)B * sizeof(int)));
+            TRY(v->stage.upload((char *)v->xd_segs.p + tab_bytes, gbase.data(), (size_t)B * sizeof(int), s));
             TRY(v->xd_x.reserve(xcm_wanted ? xm_exchange_bytes() : xd_exchange_bytes(bxt)));
             TRY(v->stage.upload(v->xd_segs.p, tab.data(), tab.size() * sizeof(XdSeg), s));
             xp.w_hh = v->w_hh; xp.w_fc1 = v->w_fc1; xp.b_fc1 = v->b_fc1; xp.w_fc2 = v->w_fc2; xp.b_fc2 = v->b_fc2;
@@ -2052,7 +2084,7 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         HIP_TRY(hipMemsetAsync(G.candg.p, 0, cg_bytes + 64, s));
         ArCall &c = calls[g];
         c = ArCall{};
-        c.Gcond = v->gcond.as<float>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
+        c.Gcond = v->gcond.as<float>(); c.gbase = v->gbase.as<int>(); c.inputs = inputs; c.wav = wav; c.mulaw = mulaw; c.logits = logits;
         c.slots = G.slot_tab.as<ArSlot>(); c.S = S; c.Sp = Spg; c.n_rep = rep[g] > 0 ? rep[g] : 1;
         c.F = T2; c.Ts = Ts; c.Lout = Lout; c.max_t = gmax[g]; c.nbt = nb; c.seed = seed; c.t_base = 0;
         if (tf) {

@@ -96,11 +96,13 @@ def encode_utterances(encoder: Encoder, mels: Sequence[torch.Tensor], want_conte
 @torch.no_grad()
 def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.Tensor], speakers: Sequence[int],
                        seed: int, utt_ids: Optional[Sequence[int]] = None, max_batch: int = 64,
-                       max_pad_frac: float = 0.25, slots: int = 0, clock=None) -> List[torch.Tensor]:
+                       max_pad_frac: float = 0.25, slots: int = 0, clock=None,
+                       mem_budget_bytes: int = 8 << 30) -> List[torch.Tensor]:
     """``convert.py:72-77`` over a list of utterances -> list of 1-D waveforms (160 * 2 * T_i' samples).
 
-    ``slots`` > 0: continuous batching -- ONE decode call over all utterances with that many decode
-    slots, each slot running utterances back to back (longest first), instead of one call per
+    ``slots`` > 0: continuous batching -- decode calls over as many utterances as ``mem_budget_bytes`` of device work space
+    allow (see ``decode_chunks``; the reference's 9 474-utterance set, ``README.md:125``, is ~35 GB of conditioning rows in one
+    call), each with that many decode slots, a slot running utterances back to back (longest first), instead of one call per
     length bucket.  The samples are the same either way (per-utterance sampling streams).
     """
     dev = next(encoder.parameters()).device
@@ -127,19 +129,47 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
         for k, i in enumerate(ids):
             out[i] = wav[k, : 2 * up * n_codes[k]]
     if slots > 0:
-        idx = torch.zeros(len(mels), max(n_codes_all), dtype=torch.int64, device=dev)
-        for i, cd in enumerate(codes):
-            idx[i, : cd.numel()] = cd
-        spk = torch.tensor([int(v) for v in speakers], device=dev)
         vocoder.set_option("slots", slots)
         try:
-            wav = generate_checked(vocoder, idx, spk, n_codes=n_codes_all, seed=seed, utt_ids=utt_ids)
+            for ids in decode_chunks(n_codes_all, mem_budget_bytes, up):
+                idx = torch.zeros(len(ids), max(n_codes_all[i] for i in ids), dtype=torch.int64, device=dev)
+                for k, i in enumerate(ids):
+                    idx[k, : codes[i].numel()] = codes[i]
+                spk = torch.tensor([int(speakers[i]) for i in ids], device=dev)
+                wav = generate_checked(vocoder, idx, spk, n_codes=[n_codes_all[i] for i in ids], seed=seed, utt_ids=[utt_ids[i] for i in ids])
+                for k, i in enumerate(ids):
+                    out[i] = wav[k, : 2 * up * n_codes_all[i]].clone() if len(ids) < len(mels) else wav[k, : 2 * up * n_codes_all[i]]
         finally:
             vocoder.set_option("slots", 0)
         if clock: clock("decode")
-        for i in range(len(mels)):
-            out[i] = wav[i, : 2 * up * n_codes_all[i]]
     return out
+
+
+# device bytes a decode call needs per conditioning frame of an utterance's own (ragged: Gcond row 3 x 896 fp32 + its compacted
+# prenet row) and per frame of the padded (B, 2 T_max) grids the prenet runs on (series 128 + gate inputs 768 + two layers' outputs
+# 2 x 256 fp32), and per output sample (fp32 waveform, padded to the call's longest utterance)
+BYTES_PER_OWN_FRAME = 4 * (3 * 896 + 256)
+BYTES_PER_PADDED_FRAME = 4 * (128 + 768 + 256 + 256)
+BYTES_PER_PADDED_SAMPLE = 4
+
+
+def decode_chunks(n_codes: Sequence[int], mem_budget_bytes: int, upsample: int = 160) -> List[List[int]]:
+    """Utterance ids, in order, cut into decode calls whose device work space stays under ``mem_budget_bytes`` (at least one
+    utterance per call).  Sizes for the reference's dimensions (``config.py:62-77``)."""
+    chunks, cur, own, tmax = [], [], 0, 0
+    for i, nc in enumerate(n_codes):
+        f = 2 * int(nc)
+        t2 = max(tmax, f)
+        need = (own + f) * BYTES_PER_OWN_FRAME + (len(cur) + 1) * t2 * (BYTES_PER_PADDED_FRAME + BYTES_PER_PADDED_SAMPLE * upsample)
+        if cur and need > mem_budget_bytes:
+            chunks.append(cur)
+            cur, own, t2 = [], 0, f
+        cur.append(i)
+        own += f
+        tmax = t2
+    if cur:
+        chunks.append(cur)
+    return chunks
 
 
 @torch.no_grad()
