@@ -128,8 +128,8 @@ def test_ragged_conditioning_allocates_the_utterances_own_frames_and_chunked_dec
     spk = synth.randint("rag/s", (8,), 102).cuda()
     wav = voc.generate(z, spk, n_codes=n_codes, seed=13, utt_ids=list(range(8)))
     ws = voc.workspace_bytes()
-    own, padded = 162 * 3 * 896 * 4, 960 * 3 * 896 * 4
-    assert own <= ws < padded, (own, ws, padded)                              # the padded Gcond alone would be 10.3 MB
+    own, padded = 162 * driver.BYTES_PER_OWN_FRAME, 960 * 3 * 896 * 4
+    assert own <= ws < padded, (own, ws, padded)                              # the padded Gcond alone would be 10.3 MB; everything now: 2.7 MB
     for i in (0, 3, 7):                                                        # ... and every utterance still equals itself decoded alone
         one = voc.generate(z[i:i + 1, : n_codes[i]], spk[i:i + 1], seed=13, utt_ids=[i])
         assert torch.equal(wav[i, : 320 * n_codes[i]], one[0]), i

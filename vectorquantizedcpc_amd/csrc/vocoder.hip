@@ -145,6 +145,7 @@ struct SeqP {
     float *cbuf;          // LSTM cell state [ndir][nbt][H*16]
     float *out;           // [B][T][ndir*H]
     const int *len;       // valid steps per utterance (nbt*16) or null = T for b < B
+    const int *row0;      // first row of every utterance in Gi / out (ragged rows) or null = b * T
     int H, nbt, B, T, ndir;
 };
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void seq_step_kernel(SeqP p, int step) {
         if (step < L) {
             act = true;
             tpos = dir == 0 ? step : L - 1 - step;
-            const float *gi = p.Gi + ((size_t)bg * p.T + tpos) * (p.ndir * G * H) + (size_t)dir * G * H + unit;
+            const float *gi = p.Gi + ((p.row0 ? (size_t)p.row0[bg] : (size_t)bg * p.T) + tpos) * (p.ndir * G * H) + (size_t)dir * G * H + unit;
             g0 = gi[0]; g1 = gi[H]; g2 = gi[2 * H];
             if (G == 3) {
                 const float *bh = p.b_hh + (size_t)dir * 3 * H + unit;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void seq_step_kernel(SeqP p, int step) {
             hn = og * tanhf(cn);
         }
         hout[hi] = hn;
-        p.out[((size_t)bg * p.T + tpos) * (p.ndir * H) + (size_t)dir * H + unit] = hn;
+        p.out[((p.row0 ? (size_t)p.row0[bg] : (size_t)bg * p.T) + tpos) * (p.ndir * H) + (size_t)dir * H + unit] = hn;
     }
 }
 
@@ -1250,13 +1251,18 @@ __global__ void ar_finalize_kernel(ArModel m, const ArCall *__restrict__ cp) {
 // the handle's host-mapped status word (bit 2; vqcpc_vocoder_check): no read-back of the indices on the host, no synchronisation.
 __global__ void glue_kernel(const int64_t *__restrict__ idx, const int64_t *__restrict__ spk,
                             const float *__restrict__ ce, const float *__restrict__ se, float *__restrict__ out,
-                            int B, int Tc, int dz, int ds, int n_codes, int n_spk, unsigned *status, unsigned status_tag) {
+                            int B, int Tc, int dz, int ds, int n_codes, int n_spk, unsigned *status, unsigned status_tag,
+                            const int *__restrict__ frames, const int *__restrict__ row0) {
     const int F = dz + ds;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * 2 * Tc * F) return;
     const int f = (int)(i % F);
     const size_t r = i / F;
     const int t2 = (int)(r % (2 * Tc)), b = (int)(r / (2 * Tc));
+    if (row0) {                                         // ragged rows: an utterance's own frames only, at its row base
+        if (t2 >= frames[b]) return;
+        i = ((size_t)row0[b] + t2) * F + f;
+    }
     if (f < dz) {
         long long z = idx[(size_t)b * Tc + t2 / 2];
         if ((z < 0 || z >= n_codes) && f == 0 && status) __hip_atomic_fetch_or(status, status_tag | 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1341,7 +1347,7 @@ struct vqcpc_vocoder {
     int two_groups = 1;                  // 0 = always one group
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf series, gi, out0, cond, condc, gcond, gbase, hseq, len;
+    DevBuf series, gi, out0, cond, gcond, gbase, hseq, len;
     DevBuf hall, a1c;                    // teacher-forced scan: h_t and fc1 outputs of one chunk
     unsigned *abort_host = nullptr;      // the handle's status word: pinned host memory the kernels write and the host reads without a HIP call
     unsigned *abort_dev = nullptr;       // the device's view of it
@@ -1416,7 +1422,7 @@ extern "C" void vqcpc_vocoder_destroy(vqcpc_vocoder *v) {
     if (v->w_hh) (void)hipFree(v->w_hh);
     if (v->Gemb4) (void)hipFree(v->Gemb4);
     if (v->bh4) (void)hipFree(v->bh4);
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->condc, &v->gcond, &v->gbase, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->gbase, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
     for (DevBuf *b : bufs) b->release();
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -1684,7 +1690,7 @@ extern "C" int vqcpc_vocoder_last_slots(vqcpc_vocoder *v) {
 extern "C" int vqcpc_vocoder_workspace_bytes(vqcpc_vocoder *v, uint64_t *bytes) {
     VQ_REQUIRE(v && bytes, "vqcpc_vocoder_workspace_bytes: null argument");
     uint64_t n = 0;
-    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->condc, &v->gcond, &v->gbase, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
+    DevBuf *bufs[] = {&v->series, &v->gi, &v->out0, &v->cond, &v->gcond, &v->gbase, &v->hseq, &v->len, &v->hall, &v->a1c, &v->xd_x, &v->xd_segs};
     for (DevBuf *b : bufs) n += b->cap;
     for (auto &G : v->grp) { DevBuf *gb[] = {&G.har, &G.a1, &G.cand_s, &G.cand_k, &G.gcur, &G.candg, &G.slot_tab, &G.cur}; for (DevBuf *b : gb) n += b->cap; }
     *bytes = n;
@@ -1699,32 +1705,24 @@ extern "C" int vqcpc_vocoder_last_timing(vqcpc_vocoder *v, float *loop_ms, int *
     return VQCPC_OK;
 }
 
-// Conditioning rows of the utterances' OWN frames only: cond (B, T2, dl) padded -> condc (sum of frames, dl), utterance b's frames
-// at rows gbase[b] .. gbase[b] + frames[b] - 1.  The Gcond GEMM then runs over those rows alone: on a ragged manifest (mean 3.4 s
-// of a 10 s maximum) two thirds of B x T_max are padding -- 5.5 GB of Gcond and the GEMM behind it for 1.9 GB of use.
-__global__ void compact_rows_kernel(const float4 *__restrict__ cond, float4 *__restrict__ condc, const int *__restrict__ frames,
-                                    const int *__restrict__ gbase, int T2, int dl4) {
-    const int b = blockIdx.y, f = blockIdx.x;
-    if (f >= frames[b]) return;
-    const float4 *src = cond + ((size_t)b * T2 + f) * dl4;
-    float4 *dst = condc + ((size_t)gbase[b] + f) * dl4;
-    for (int c = threadIdx.x; c < dl4; c += blockDim.x) dst[c] = src[c];
-}
-
-// conditioning: glue -> 2-layer bi-GRU prenet -> cond (B, 2Tc, 2Hp); lens_dev = valid frames per utterance
+// conditioning: glue -> 2-layer bi-GRU prenet -> cond.  Dense (frames_dev == row0_dev == nullptr): cond (B, 2Tc, 2Hp), every
+// utterance 2 Tc frames.  Ragged: frames_dev[b] valid frames per utterance, row0_dev[b] its first row, n_rows = their sum -- every
+// buffer of the prenet (series, hoisted gate inputs, both layers' outputs) holds the utterances' OWN frames only, utterance b at
+// rows row0[b] ..: on a manifest of 1 - 10 s utterances (mean 3.4 s) two thirds of B x T_max would be padding.
 static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int B, int Tc,
-                         const int *frames_dev, float *cond_out, hipStream_t s) {
+                         const int *frames_dev, const int *row0_dev, size_t n_rows, float *cond_out, hipStream_t s) {
     const auto &d = v->d;
     const int F = d.dz + d.ds, Hp = d.Hp, dl = 2 * Hp, T2 = 2 * Tc, nbt = (B + 15) / 16;
-    const size_t rows = (size_t)B * T2;
+    const size_t rows = row0_dev ? (n_rows ? n_rows : 1) : (size_t)B * T2;
     TRY(v->series.reserve(rows * F * sizeof(float)));
     TRY(v->gi.reserve(rows * 6 * Hp * sizeof(float)));
     TRY(v->out0.reserve(rows * dl * sizeof(float)));
     const size_t hsz = (size_t)2 * nbt * Hp * 16 * sizeof(float);
     TRY(v->hseq.reserve(2 * hsz));
-    const size_t ng = rows * F;
+    const size_t ng = (size_t)B * T2 * F;
     hipLaunchKernelGGL(glue_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, idx, spk, v->code_emb,
-                       v->spk_emb, v->series.as<float>(), B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers, v->abort_dev, v->epoch << 8);
+                       v->spk_emb, v->series.as<float>(), B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers, v->abort_dev, v->epoch << 8,
+                       frames_dev, row0_dev);
     v->persist_pending = true;            // an index outside its table is reported through the status word
     for (int l = 0; l < 2; ++l) {
         const float *xin = l == 0 ? v->series.as<float>() : v->out0.as<float>();
@@ -1732,10 +1730,10 @@ static int run_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *sp
         float *xout = l == 0 ? v->out0.as<float>() : cond_out;
         TRY(vq_gemm_chain(xin, I, v->p_wih[l], v->p_bih[l], v->gi.as<float>(), 6 * Hp, (int)rows, 6 * Hp, I, I, s));
         HIP_TRY(hipMemsetAsync(v->hseq.p, 0, 2 * hsz, s));
-        if (frames_dev) HIP_TRY(hipMemsetAsync(xout, 0, rows * dl * sizeof(float), s));
+        if (frames_dev && !row0_dev) HIP_TRY(hipMemsetAsync(xout, 0, rows * dl * sizeof(float), s));      // dense rows past an utterance's end
         SeqP q{};
         q.Wf = v->p_wf[l]; q.b_hh = v->p_bhh[l]; q.Gi = v->gi.as<float>(); q.hbuf = v->hseq.as<float>();
-        q.out = xout; q.len = frames_dev; q.H = Hp; q.nbt = nbt; q.B = B; q.T = T2; q.ndir = 2;
+        q.out = xout; q.len = frames_dev; q.row0 = row0_dev; q.H = Hp; q.nbt = nbt; q.B = B; q.T = T2; q.ndir = 2;
         for (int t = 0; t < T2; ++t) TRY(launch_seq<3>(q, t, s));
     }
     HIP_TRY(hipGetLastError());
@@ -1908,11 +1906,9 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
     // per-utterance lengths: frames for the prenet, samples for the AR loop
     std::vector<int> lens(2 * Bp, 0);     // [frames | samples]
     std::vector<unsigned> utt(B);
-    bool ragged = false;
     for (int b = 0; b < B; ++b) {
         int nc = n_codes_host ? n_codes_host[b] : Tc;
         VQ_REQUIRE(nc >= 0 && nc <= Tc, "vocoder: n_codes[%d] = %d outside [0, %d]", b, nc, Tc);
-        ragged |= nc != Tc;
         lens[b] = 2 * nc;
         int ns = d.upsample_t * 2 * nc;
         if (inputs) ns = ns < Ts ? ns : Ts;
@@ -1984,29 +1980,19 @@ static int run_ar(vqcpc_vocoder *v, const int64_t *idx, const int64_t *spk, int 
         TRY(v->stage.upload(v->grp[g].slot_tab.p, table[g].data(), table[g].size() * sizeof(ArSlot), s));
         TRY(v->stage.upload(v->grp[g].cur.p, table[g].data(), (size_t)tiles[g] * 16 * sizeof(ArSlot), s));
     }
-    const int *frames_dev = ragged ? v->len.as<int>() : nullptr;
-
-    // Gcond over every utterance's own frames (ragged): row base of utterance b = prefix sum of the frame counts
-    std::vector<int> gbase(B);
+    // Conditioning over every utterance's own frames (ragged rows): row base of utterance b = prefix sum of the frame counts
+    std::vector<int> gbase(Bp, 0);
     long grows = 0;
     for (int b = 0; b < B; ++b) { gbase[b] = (int)grows; grows += lens[b]; }
     VQ_REQUIRE(grows < (1L << 31), "vocoder: %ld conditioning frames in one call", grows);
-    TRY(v->gbase.reserve((size_t)B * sizeof(int)));
-    TRY(v->stage.upload(v->gbase.p, gbase.data(), (size_t)B * sizeof(int), s));
-    const size_t rows = (size_t)B * T2;
-    TRY(v->cond.reserve(rows * dl * sizeof(float)));
-    TRY(run_condition(v, idx, spk, B, Tc, frames_dev, v->cond.as<float>(), s));
+    TRY(v->gbase.reserve((size_t)Bp * sizeof(int)));
+    TRY(v->stage.upload(v->gbase.p, gbase.data(), (size_t)Bp * sizeof(int), s));
     const size_t crows = grows > 0 ? (size_t)grows : 1;
+    TRY(v->cond.reserve(crows * dl * sizeof(float)));
+    TRY(run_condition(v, idx, spk, B, Tc, v->len.as<int>(), v->gbase.as<int>(), (size_t)grows, v->cond.as<float>(), s));
     TRY(v->gcond.reserve(crows * 3 * Hr * sizeof(float)));
-    const float *cond_rows = v->cond.as<float>();
-    if (ragged) {
-        TRY(v->condc.reserve(crows * dl * sizeof(float)));
-        hipLaunchKernelGGL(compact_rows_kernel, dim3(T2, B), dim3(64), 0, s, (const float4 *)v->cond.p, (float4 *)v->condc.p, v->len.as<int>(),
-                           v->gbase.as<int>(), T2, dl / 4);
-        cond_rows = v->condc.as<float>();
-    }
     if (grows > 0)
-        TRY(vq_gemm_chain(cond_rows, dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)grows, 3 * Hr, dl, dl, s));
+        TRY(vq_gemm_chain(v->cond.as<float>(), dl, v->w_cond, v->b_ih, v->gcond.as<float>(), 3 * Hr, (int)grows, 3 * Hr, dl, dl, s));
     if (wav) HIP_TRY(hipMemsetAsync(wav, 0, (size_t)B * Lout * sizeof(float), s));
     if (mulaw) HIP_TRY(hipMemsetAsync(mulaw, 0, (size_t)B * Lout * sizeof(int64_t), s));
 
@@ -2252,7 +2238,7 @@ extern "C" int vqcpc_vocoder_glue(vqcpc_vocoder *v, const int64_t *idx, const in
     const auto &d = v->d;
     const size_t ng = (size_t)B * 2 * Tc * (d.dz + d.ds);
     hipLaunchKernelGGL(glue_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, speaker, v->code_emb,
-                       v->spk_emb, series, B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers, v->abort_dev, v->epoch << 8);
+                       v->spk_emb, series, B, Tc, d.dz, d.ds, d.n_codes, d.n_speakers, v->abort_dev, v->epoch << 8, nullptr, nullptr);
     v->persist_pending = true;
     HIP_TRY(hipGetLastError());
     return VQCPC_OK;
@@ -2261,5 +2247,5 @@ extern "C" int vqcpc_vocoder_glue(vqcpc_vocoder *v, const int64_t *idx, const in
 extern "C" int vqcpc_vocoder_condition(vqcpc_vocoder *v, const int64_t *idx, const int64_t *speaker, int B, int Tc,
                                        float *cond, void *stream) {
     VQ_REQUIRE(v && idx && speaker && cond && B > 0 && Tc > 0, "vqcpc_vocoder_condition: bad argument");
-    return run_condition(v, idx, speaker, B, Tc, nullptr, cond, (hipStream_t)stream);
+    return run_condition(v, idx, speaker, B, Tc, nullptr, nullptr, 0, cond, (hipStream_t)stream);
 }

@@ -145,11 +145,11 @@ def convert_utterances(encoder: Encoder, vocoder: Vocoder, mels: Sequence[torch.
     return out
 
 
-# device bytes a decode call needs per conditioning frame of an utterance's own (ragged: Gcond row 3 x 896 fp32 + its compacted
-# prenet row) and per frame of the padded (B, 2 T_max) grids the prenet runs on (series 128 + gate inputs 768 + two layers' outputs
-# 2 x 256 fp32), and per output sample (fp32 waveform, padded to the call's longest utterance)
-BYTES_PER_OWN_FRAME = 4 * (3 * 896 + 256)
-BYTES_PER_PADDED_FRAME = 4 * (128 + 768 + 256 + 256)
+# device bytes a decode call needs per conditioning frame of an utterance's OWN (ragged rows: glue series 128 + hoisted gate
+# inputs 768 + two prenet layers' outputs 2 x 256 + the Gcond row 3 x 896, fp32), and per code / output sample of the padded
+# (B, T_max) grids that remain (int64 code indices, fp32 waveform)
+BYTES_PER_OWN_FRAME = 4 * (128 + 768 + 256 + 256 + 3 * 896)
+BYTES_PER_PADDED_FRAME = 4                  # half an int64 code index
 BYTES_PER_PADDED_SAMPLE = 4
 
 
