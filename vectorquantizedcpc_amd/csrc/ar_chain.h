@@ -127,26 +127,32 @@ __device__ __forceinline__ void chain_phase(float &acc, const float (&hv)[8], co
 }
 
 // Lane layout of a chain wave: lane = 16 R + 4 kw + j; R = 2 rq + c0.  The quad (j = 0..3) holds chain (kw, c0) of rows
-// 4 rq + j.  Operand values of a chain sit in LDS in chain order ([cid = 2 kw + c0][n]); they are used in PHASES of 32
+// 4 rq + j.  Operand values of a chain sit in LDS chain by chain ([cid = 2 kw + c0][...]); they are used in PHASES of 32
 // terms: in phase ph quad lane j holds terms 32 ph + 8 j .. + 7 (two 16-byte LDS words), so term n comes from quad lane
 // (n % 32) / 8, register n % 8 -- 8 operand registers per phase instead of NT / 4 for the whole chain.  A last phase of 16
 // terms (NT = 112) gives every lane 4.
+// LDS order inside a phase: the four lanes' FIRST words, then their SECOND words (term 32 ph + 8 j + r sits at 32 ph + 16 (r / 4)
+// + 4 j + r % 4), so that one ds_read_b128 of a quad covers 16 contiguous floats and the four chains of a 16-lane group (chain
+// stride 112 or 48 floats = 48 mod 64 banks) cover all 64 banks: with the terms in plain order (lane j at 8 j) a quad's read had
+// holes and chains cid / cid + 4 shared banks -- rocprofv3 counted 59 % of the LDS cycles of ar_xcd_kernel<4> as bank conflicts
+// (profiles/r04_pmc_sq_xcd32.json, round 4's first pass).
+// (the 16-term last phase of a 112-term chain keeps its plain order: lane j's one word at 4 j)
+template <int NT>
+__device__ __forceinline__ int phase_pos_t(int n) { return (NT % 32 != 0 && n >= NT - NT % 32) ? n : ((n & ~31) + ((n >> 2) & 1) * 16 + ((n >> 3) & 3) * 4 + (n & 3)); }
 template <int NT>
 __device__ __forceinline__ float chain_regs(const float *w, const float *opnd) {
     float acc = 0.f;
     constexpr int NPH = (NT + 31) / 32;
-    float4 cur[2], nxt[2];
-    const float4 *op = (const float4 *)opnd;            // this lane's first word of phase 0: opnd = base + cid * NT + 8 j
-    cur[0] = op[0]; cur[1] = op[1];
+    float4 cur[2], nxt[2];                              // opnd = base + cid * stride + 4 j: this lane's first word of phase 0
+    cur[0] = *(const float4 *)opnd; cur[1] = *(const float4 *)(opnd + 16);
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
-        constexpr int dummy = 0; (void)dummy;
         const int len = NT - 32 * ph < 32 ? NT - 32 * ph : 32;          // 32, or 16 in the last phase of 112
         if (ph + 1 < NPH) {
             const int nlen = NT - 32 * (ph + 1) < 32 ? NT - 32 * (ph + 1) : 32;
-            if (nlen == 32) { nxt[0] = op[8 * (ph + 1)]; nxt[1] = op[8 * (ph + 1) + 1]; }
-            // a 16-term phase: lane j holds terms 4 j .. 4 j + 3; opnd points at word 2 j of the chain -> word 8 (ph + 1) + j is (j words back)
-            else { nxt[0] = *(const float4 *)(opnd + 32 * (ph + 1) - 4 * (int)(threadIdx.x & 3)); nxt[1] = nxt[0]; }
+            nxt[0] = *(const float4 *)(opnd + 32 * (ph + 1));
+            // a 16-term phase: lane j holds terms 4 j .. 4 j + 3 = its first word; there is no second
+            nxt[1] = nlen == 32 ? *(const float4 *)(opnd + 32 * (ph + 1) + 16) : nxt[0];
         }
         const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
         if (len == 32) chain_phase<32>(acc, hv, w + 32 * ph);
@@ -155,14 +161,17 @@ __device__ __forceinline__ float chain_regs(const float *w, const float *opnd) {
     }
     return acc;
 }
-// The same chain for ONE or TWO operand vectors (two decode slots) with its weights streamed from LDS ([NT] floats at wp,
-// chain order) a phase ahead of their use: a service wave must not hold 112 weights next to everything else it keeps.
-// w0 = the weights of phase 0, already in registers (requested before the barrier the chain waits behind).
+// The same chain for ONE or TWO operand vectors (two decode slots) with its weights streamed from LDS a phase ahead of their use: a
+// service wave must not hold 112 weights next to everything else it keeps.  The weights of a lane's chain are NT / 4 16-byte words,
+// word i at wp[i * WS]: the words of the WS lane-chains of a wave are interleaved ([word][lane-chain]), so that a wave's read of word
+// i is one contiguous run -- with a lane's chain contiguous ([lane-chain][NT], 448 bytes apart) the sixteen lanes of a read group hit
+// four bank windows four ways each.  w0 = the weights of phase 0, already in registers (requested before the barrier the chain waits
+// behind).
 __device__ __forceinline__ void load_phase(const float *opnd, int ph, int nlen, float4 (&d)[2]) {
-    if (nlen == 32) { d[0] = ((const float4 *)opnd)[8 * ph]; d[1] = ((const float4 *)opnd)[8 * ph + 1]; }
-    else { d[0] = *(const float4 *)(opnd + 32 * ph - 4 * (int)(threadIdx.x & 3)); d[1] = d[0]; }     // 16-term phase: lane j holds terms 4 j .. 4 j + 3
+    d[0] = *(const float4 *)(opnd + 32 * ph);
+    d[1] = nlen == 32 ? *(const float4 *)(opnd + 32 * ph + 16) : d[0];     // 16-term phase: lane j holds terms 4 j .. 4 j + 3 = the first word
 }
-template <int NT>
+template <int NT, int WS>
 __device__ __forceinline__ void chain_lds2(const float4 *wp, const float4 (&w0)[8], const float *opA, const float *opB, bool two,
                                            float &accA, float &accB) {
     constexpr int NPH = (NT + 31) / 32;
@@ -181,7 +190,7 @@ __device__ __forceinline__ void chain_lds2(const float4 *wp, const float4 (&w0)[
             load_phase(opA, ph + 1, nlen, nxtA);
             if (two) load_phase(opB, ph + 1, nlen, nxtB);
 #pragma unroll
-            for (int i = 0; i < nlen / 4; ++i) wn[i] = wp[8 * (ph + 1) + i];
+            for (int i = 0; i < nlen / 4; ++i) wn[i] = wp[(8 * (ph + 1) + i) * WS];
         }
         __builtin_amdgcn_sched_barrier(0);
         float wv[32];
@@ -204,6 +213,9 @@ __device__ __forceinline__ void chain_lds2(const float4 *wp, const float4 (&w0)[
     }
 }
 
+// the lane of a chain wave that holds chain cc (= 2 kw + c0) of the wave's row rr (0..7): inverse of the lane layout above
+__device__ __forceinline__ unsigned xd_lane_of(unsigned rr, unsigned cc) { return 16u * (2u * (rr >> 2) + (cc & 1u)) + 4u * (cc >> 1) + (rr & 3u); }
+
 // Row sum from the 8 chain lanes of a row: a0 + a1 across the two 16-lane rows of an rq pair (lane ^ 16), then
 // ((q0 + q1) + q2) + q3 along the K quarters (lane + 4, + 8, + 12 inside the row) -- the order of the MFMA kernels.
 // Meaningful in lanes with kw == 0 (either c0 row).
@@ -214,11 +226,12 @@ __device__ __forceinline__ float chain_combine(float acc) {
     return ((q + q1) + q2) + q3;
 }
 
-// position of operand column k in the chain-ordered LDS copy (inverse of chain_col): [cid][n]
-__device__ __forceinline__ int chain_pos(int NS, int k) {
+// position of operand column k in the LDS copy (inverse of chain_col): chain cid = 2 kw + c0 at cid * stride, term n at phase_pos(n)
+template <int NS>
+__device__ __forceinline__ int chain_pos(int k, int stride) {
     const int S = k >> 4, kw = S / NS, s = S - kw * NS;
     const int q = (k >> 2) & 3, c0 = k & 1, ci = (k >> 1) & 1;
-    return (2 * kw + c0) * (8 * NS) + 8 * s + 4 * ci + q;
+    return (2 * kw + c0) * stride + phase_pos_t<8 * NS>(8 * s + 4 * ci + q);
 }
 
 }  // namespace

@@ -59,12 +59,12 @@ namespace {
 // LDS carve, in floats (ints behind them)
 template <int BXT> struct Lds {
     static constexpr int gemb = 0;                        // [NC][3][UPB]   slice of the sample-embedding table
-    static constexpr int fc1w = gemb + NC * ROWS;         // [FPB][8 chains][112]
-    static constexpr int fc2w = fc1w + FPB * HR;          // [FPB][8 chains][32]
-    static constexpr int whx = fc2w + FPB * HF;           // [4][8 chains][112]  W_hh rows 80..83 (the chain waves hold rows 0..79)
+    static constexpr int fc1w = gemb + NC * ROWS;         // [28 words][64 lane-chains (row r8, chain cid)][4]: word-interleaved (chain_lds2)
+    static constexpr int fc2w = fc1w + FPB * HR;          // [8 words][64 lane-chains][4]
+    static constexpr int whx = fc2w + FPB * HF;           // [28 words][32 lane-chains][4]  W_hh rows 80..83 (the chain waves hold rows 0..79)
     static constexpr int hc = whx + 4 * HR;               // [BXT][HR]  h_t, chain order
-    static constexpr int ac = hc + BXT * HR;              // [BXT][HF]  a_t, chain order
-    static constexpr int gsum = ac + BXT * HF;            // [BXT][96]  W_hh h of the owned rows [gate][unit]
+    static constexpr int ac = hc + BXT * HR;              // [BXT][8 chains][AS]  a_t (32 terms per chain, chain stride AS = 48: bank windows)
+    static constexpr int gsum = ac + BXT * 8 * 48;            // [BXT][96]  W_hh h of the owned rows [gate][unit]
     static constexpr int noise = gsum + BXT * 96;         // [2][BXT][8] Gumbel noise of the step in flight / the next one
     static constexpr int mtab = noise + 2 * BXT * 8;      // [NC] mu-law decode table
     static constexpr int bq = mtab + NC;                  // [3][32] b_hh of the owned units
@@ -134,15 +134,15 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     }
     for (unsigned e = tid; e < FPB * HR; e += THREADS) {
         const unsigned rr = e / HR, rem = e - rr * HR, cc = rem / NT_H, n = rem - cc * NT_H;
-        fc1w[e] = p.w_fc1[(size_t)(FPB * rank + rr) * HR + chain_col(HR / 64, cc >> 1, cc & 1, n)];
+        fc1w[((n >> 2) * 64 + xd_lane_of(rr, cc)) * 4 + (n & 3)] = p.w_fc1[(size_t)(FPB * rank + rr) * HR + chain_col(HR / 64, cc >> 1, cc & 1, n)];
     }
     for (unsigned e = tid; e < FPB * HF; e += THREADS) {
         const unsigned rr = e / HF, rem = e - rr * HF, cc = rem / NT_A, n = rem - cc * NT_A;
-        fc2w[e] = p.w_fc2[(size_t)(FPB * rank + rr) * HF + chain_col(HF / 64, cc >> 1, cc & 1, n)];
+        fc2w[((n >> 2) * 64 + xd_lane_of(rr, cc)) * 4 + (n & 3)] = p.w_fc2[(size_t)(FPB * rank + rr) * HF + chain_col(HF / 64, cc >> 1, cc & 1, n)];
     }
     for (unsigned e = tid; e < 4 * HR; e += THREADS) {                 // W_hh rows 80..83 = gate 2 (n), units 24..27
         const unsigned rr = e / HR, rem = e - rr * HR, cc = rem / NT_H, n = rem - cc * NT_H;
-        whx[e] = p.w_hh[(size_t)(2 * HR + UPB * rank + 24 + rr) * HR + chain_col(HR / 64, cc >> 1, cc & 1, n)];
+        whx[((n >> 2) * 32 + (xd_lane_of(rr, cc) & 31u)) * 4 + (n & 3)] = p.w_hh[(size_t)(2 * HR + UPB * rank + 24 + rr) * HR + chain_col(HR / 64, cc >> 1, cc & 1, n)];
     }
     for (unsigned e = tid; e < NC; e += THREADS) mtab[e] = p.mulaw_tab[e];
     for (unsigned e = tid; e < 96; e += THREADS) { const unsigned g = e >> 5, u = e & 31; c_bq[e] = u < UPB ? p.b_hh[g * HR + UPB * rank + u] : 0.f; }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     // h_t gather: every thread takes column tid of every slot, the first 128 threads also column 768 + tid
     const unsigned hk1 = tid, hk2 = THREADS + (tid & 127u);
     const unsigned hoff1 = ((((hk1 / UPB) * BXT) << 5) + hk1 % UPB) * 8u, hoff2 = ((((hk2 / UPB) * BXT) << 5) + hk2 % UPB) * 8u;
-    const unsigned hdst1 = chain_pos(HR / 64, hk1), hdst2 = chain_pos(HR / 64, hk2);
+    const unsigned hdst1 = chain_pos<HR / 64>(hk1, NT_H), hdst2 = chain_pos<HR / 64>(hk2, NT_H);
     const bool two = tid < HR - THREADS;
 #define XD_SWEEP_H()                                                                                              \
     do {                                                                                                          \
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         }                                                                                                         \
     } while (0)
 
-    const float *opnd = hc + cid * NT_H + 8 * j;
+    const float *opnd = hc + cid * NT_H + 4 * j;
     bool fc1_role = false;
     if constexpr (BXT == 1) fc1_role = wave == 1;
     if (fc1_role) {
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         const bool fc2_wave = cw < bx;
         const int fc2_after = bx < 3 ? bx : 3;                             // chains done before it looks for a_t
         const float b2 = p.b_fc2[FPB * rank + r8];
-        const float4 *wp2 = (const float4 *)(fc2w + (r8 * 8 + cid) * NT_A);
-        const float *opnd2 = ac + cw * HF + cid * NT_A + 8 * j;
+        const float4 *wp2 = (const float4 *)fc2w + lane;                   // word i of this lane's chain at wp2[64 i]
+        const float *opnd2 = ac + cw * (8 * 48) + cid * 48 + 4 * j;
         ps_barrier();                                                      // state and noise of step 0 posted
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 if (fc2_wave && b + 1 == fc2_after) {
                     // ---- a_t of slot `wave` (256 granules, 4 per lane) -> fc2 -> Gumbel-max candidate of the 8 owned classes
                     const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
-                    const unsigned adst = (lane & 1u) * NT_A + 8 * (lane >> 4) + 4 * ((lane >> 1) & 1u) + ((lane >> 2) & 3u);
-                    float4 wa = wp2[0], wb = wp2[1];                     // first weights and the noise: on their way during the sweep
+                    const unsigned adst = (unsigned)chain_pos<HF / 64>((int)lane, 48);      // a_t[lane + 64 i]: chain 2 i + (lane & 1), i.e. 96 i further
+                    float4 wa = wp2[0], wb = wp2[64];                    // first weights and the noise: on their way during the sweep
                     unsigned lno = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id, from the hardware
                     asm volatile("" : "+v"(lno));      // opaque, and rebuilt: the hoisted address of this read -- then r8, then the lane id
                     const unsigned r8o = ((lno >> 5) << 2) | (lno & 3u);      // itself -- was spilled to scratch and reloaded at every step
@@ -258,15 +258,15 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                         if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ac[cw * HF + 64 * i + adst] = __uint_as_float((unsigned)va[i]);
+                    for (int i = 0; i < 4; ++i) ac[cw * (8 * 48) + 96 * i + adst] = __uint_as_float((unsigned)va[i]);
                     XD_STAMP(2, 8);
-                    const float4 a0 = ((const float4 *)opnd2)[0], a1 = ((const float4 *)opnd2)[1];
+                    const float4 a0 = *(const float4 *)opnd2, a1 = *(const float4 *)(opnd2 + 16);
                     const float hv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                     float acc2 = 0.f;
 #pragma unroll
                     for (int J = 0; J < 4; ++J) {                            // 32 terms: 8 per quad lane, weights two 16-byte words at a time
                         float4 na = wa, nb2 = wb;
-                        if (J < 3) { na = wp2[2 * J + 2]; nb2 = wp2[2 * J + 3]; }
+                        if (J < 3) { na = wp2[64 * (2 * J + 2)]; nb2 = wp2[64 * (2 * J + 3)]; }
                         const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
                         if (J == 0) fmac8<0>(acc2, hv, w8);
                         if (J == 1) fmac8<1>(acc2, hv, w8);
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         const int n_own = bx > sv ? (bx - sv + 1) / 2 : 0;              // slots sv, sv + 2 < bx
         const bool cell_on = cb < bx;
         const float b1 = p.b_fc1[FPB * rank + r8];
-        const float4 *wp1 = (const float4 *)(fc1w + (r8 * 8 + cid) * NT_H);
-        const float4 *wpx = (const float4 *)(whx + ((r8 & 3u) * 8 + cid) * NT_H);
+        const float4 *wp1 = (const float4 *)fc1w + lane;                   // word i of this lane's chain at wp1[64 i]
+        const float4 *wpx = (const float4 *)whx + (lane & 31u);            // rows 80..83: both half waves read the same 32 lane-chains, word i at wpx[32 i]
         const float bq0 = c_bq[cu], bq1 = c_bq[32 + cu], bq2 = c_bq[64 + cu];
         const u64 *csrc = gc + ((lane & 31u) * 16 + (unsigned)(cb < BXT ? cb : 0));
         // W_hh rows 80..83 for the other wave's slots 1 - sv and 3 - sv: the lower half wave takes the first, the upper half the second
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             advance(t + 1);
             float4 w1p[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w1p[i] = wp1[i];
+            for (int i = 0; i < 8; ++i) w1p[i] = wp1[64 * i];
             XD_SWEEP_H();
             XD_STAMP(0, 3);
             ps_barrier();                                                // A: h_t in LDS
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             // ---- fc1 of the own slots (both together: every weight is used for both and then dropped); one slot per XCD: wave 1
             if (BXT > 1 && n_own > 0) {
                 float accA, accB;
-                chain_lds2<NT_H>(wp1, w1p, opnd + sv * HR, opnd + (sv + 2 < BXT ? sv + 2 : sv) * HR, n_own > 1, accA, accB);
+                chain_lds2<NT_H, 64>(wp1, w1p, opnd + sv * HR, opnd + (sv + 2 < BXT ? sv + 2 : sv) * HR, n_own > 1, accA, accB);
                 float v = chain_combine(accA);
                 v += b1;
                 v = v > 0.f ? v : 0.f;
@@ -439,9 +439,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             if (xb0 < bx) {
                 float4 wx0[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wx0[i] = wpx[i];
+                for (int i = 0; i < 8; ++i) wx0[i] = wpx[32 * i];
                 float acc, unused;
-                chain_lds2<NT_H>(wpx, wx0, opndx, opndx, false, acc, unused);
+                chain_lds2<NT_H, 32>(wpx, wx0, opndx, opndx, false, acc, unused);
                 const float v = chain_combine(acc);
                 if (sum_lane && (lane < 32 || x_two)) gsum[xslot * 96 + 80 + (r8 & 3u)] = v;
             }

@@ -712,7 +712,6 @@ __device__ __forceinline__ bool rows16_dump(const FusedP &p, const float *tile, 
 // for 13.7 us of MFMAs (tools/encoder_stage_times.py); a second wave fills those gaps, and LayerNorm has a half-wave per row.
 __global__ __launch_bounds__(512) void enc_fused_kernel(FusedP p) {
     __shared__ __attribute__((aligned(16))) float tile[16 * FE_LD];
-    __shared__ __attribute__((aligned(16))) float tile2[16 * FE_LD];
     __shared__ VqSmem sm;
     __shared__ float mel_win[FE_WIN_C * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * 16;
@@ -760,35 +759,32 @@ __global__ __launch_bounds__(512) void enc_fused_kernel(FusedP p) {
     }
     __syncthreads();
 
-    // Two activation tiles, ping-pong: a stage's MFMAs read one and its results go straight into the other (nobody reads that one:
-    // the barrier between "every wave has read its A operands" and the store is gone -- two barriers per layer instead of three).
-    float *cur = tile, *nxt = tile2;
-    rows16_gemm<NT, RD>(cur, p.conv_f, NT * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane, fr);
+    rows16_gemm<NT, RD>(tile, p.conv_f, NT * wave, K0 / 16, p.conv_mode == 1 ? K0 / 16 : 4, nullptr, tot, lane, fr);
     if (p.stage != 0) rows16_prefetch<NT, RD>(p.fc_f[0], NT * wave, 32, fr, lane);    // under the store + LayerNorm below
-    rows16_store<NT>(nxt, tot, NT * wave, lane);
+    __syncthreads();                                     // every wave has read its A operands
+    rows16_store<NT>(tile, tot, NT * wave, lane);
     __syncthreads();
-    if (rows16_dump(p, nxt, 0, r0, tid)) return;
+    if (rows16_dump(p, tile, 0, r0, tid)) return;
 
     // ---- seg-FC stack (model.py:46-55)
-    rows16_layernorm<1>(nxt, p.ln_g[0], p.ln_b[0], p.eps, p.lnc, tid);
+    rows16_layernorm<1>(tile, p.ln_g[0], p.ln_b[0], p.eps, p.lnc, tid);
     __syncthreads();
-    if (rows16_dump(p, nxt, 1, r0, tid)) return;
-    { float *sw = cur; cur = nxt; nxt = sw; }
+    if (rows16_dump(p, tile, 1, r0, tid)) return;
     for (int l = 0; l < 4; ++l) {
-        rows16_gemm<NT, RD>(cur, p.fc_f[l], NT * wave, 32, 16, nullptr, tot, lane, fr);
+        rows16_gemm<NT, RD>(tile, p.fc_f[l], NT * wave, 32, 16, nullptr, tot, lane, fr);
         if (l < 3) rows16_prefetch<NT, RD>(p.fc_f[l + 1], NT * wave, 32, fr, lane);
-        rows16_store<NT>(nxt, tot, NT * wave, lane);
         __syncthreads();
-        if (rows16_dump(p, nxt, 2 + 2 * l, r0, tid)) return;
-        rows16_layernorm<1>(nxt, p.ln_g[l + 1], p.ln_b[l + 1], p.eps, p.lnc, tid);
+        rows16_store<NT>(tile, tot, NT * wave, lane);
         __syncthreads();
-        if (rows16_dump(p, nxt, 3 + 2 * l, r0, tid)) return;
-        { float *sw = cur; cur = nxt; nxt = sw; }
+        if (rows16_dump(p, tile, 2 + 2 * l, r0, tid)) return;
+        rows16_layernorm<1>(tile, p.ln_g[l + 1], p.ln_b[l + 1], p.eps, p.lnc, tid);
+        __syncthreads();
+        if (rows16_dump(p, tile, 3 + 2 * l, r0, tid)) return;
     }
 
     // ---- encoder.14: 512 -> 64 with bias: four 16-column tiles.  The reference's fold (bias + c0) + c1 has two independent
     // zero-started chains (k < 256, k >= 256): wave w runs c0 of tile w, wave w + 4 runs c1 -- half the dependent MFMA chain
-    // each -- and hands it over through LDS (the other activation tile, which is dead).  The VQ codebook tiles stream in underneath.
+    // each -- and hands it over through LDS.  The VQ codebook tiles stream in underneath.
     const int ctw = wave & 3, kh = wave >> 2;
     const int nwv = p.n_emb % 128 == 0 ? 8 : 4;          // waves of the VQ search
     const int tpw = p.n_emb / (16 * nwv), t0 = (wave < nwv ? wave : 0) * tpw;
@@ -800,8 +796,9 @@ __global__ __launch_bounds__(512) void enc_fused_kernel(FusedP p) {
     f32x4 zt[1];
     float4 fr1[4][1];
     rows16_prefetch<1, 4>(p.out_f, ctw, 16, fr1, lane, 16 * kh, 32);
-    rows16_gemm<1, 4>(cur, p.out_f, ctw, 16, 16, kh == 0 ? p.out_b : nullptr, zt, lane, fr1, 16 * kh, 32);
-    float (*c1s)[68] = (float (*)[68])nxt;
+    rows16_gemm<1, 4>(tile, p.out_f, ctw, 16, 16, kh == 0 ? p.out_b : nullptr, zt, lane, fr1, 16 * kh, 32);
+    float (*c1s)[68] = (float (*)[68])tile;              // the activation tile is dead once every wave is past its chain
+    __syncthreads();
     if (kh == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) c1s[4 * (lane >> 4) + r][16 * ctw + (lane & 15)] = zt[0][r];
