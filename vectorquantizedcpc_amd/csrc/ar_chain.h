@@ -19,7 +19,7 @@ constexpr int NT_A = HF / 8;           // terms of a chain over a: 32
 // exchange area of one XCD, in granules
 __host__ __device__ constexpr int xg_h(int bxt) { return NW * bxt * 32; }         // [rank][slot][32] (28 used: two whole lines)
 __host__ __device__ constexpr int xg_a(int bxt) { return NW * bxt * FPB; }        // [rank][slot][8]
-__host__ __device__ constexpr int xg_c() { return NW * 16; }                      // [rank][16] (one line per rank)
+__host__ __device__ constexpr int xg_c() { return NW * 16; }                      // [slot < 16][rank]: a slot's 32 candidates are contiguous
 __host__ __device__ constexpr int xg_region(int bxt) { return xg_h(bxt) + xg_a(bxt) + xg_c(); }
 constexpr int CTL_WORDS = 64;          // u32: arrivals per XCC [0..7], total [8]
 

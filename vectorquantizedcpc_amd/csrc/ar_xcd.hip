@@ -286,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     }
                     const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
                     if (lane == 0 && !drop)
-                        xd_put(gc, ((unsigned)rank * 16 + cw) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                        xd_put(gc, ((unsigned)cw * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
                     XD_STAMP(2, 9);
                 }
             }
@@ -310,7 +310,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         const float4 *wp1 = (const float4 *)fc1w + lane;                   // word i of this lane's chain at wp1[64 i]
         const float4 *wpx = (const float4 *)whx + (lane & 31u);            // rows 80..83: both half waves read the same 32 lane-chains, word i at wpx[32 i]
         const float bq0 = c_bq[cu], bq1 = c_bq[32 + cu], bq2 = c_bq[64 + cu];
-        const u64 *csrc = gc + ((lane & 31u) * 16 + (unsigned)(cb < BXT ? cb : 0));
+        // the slot's 32 candidates are contiguous ([slot][worker]: a half wave's poll reads two lines, not one line per worker -- 1.6 % of a
+        // single-utterance step, 0.7 % at 32 utterances: profiles/r04_ab_lds_layout_and_encoder_pingpong.txt)
+        const u64 *csrc = gc + ((unsigned)(cb < BXT ? cb : 0) * NW + (lane & 31u));
         // W_hh rows 80..83 for the other wave's slots 1 - sv and 3 - sv: the lower half wave takes the first, the upper half the second
         const int xb0 = BXT == 1 ? 0 : 1 - sv;                            // one slot per XCD: wave 0 takes them itself (wave 1 is fc1)
         const bool x_two = xb0 + 2 < bx;
