@@ -27,7 +27,7 @@ voc = V.Vocoder(V.ConfVocoder())
 voc.load_state_dict(synth.vocoder_state_dict())
 voc = voc.cuda().eval()
 voc.set_option("xcd", 1)
-for B in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 32]:
+for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 16, 32]:
     z = synth.randint("timeline", (B, 4), 512).cuda()
     spk = torch.zeros(B, dtype=torch.long, device="cuda")
     voc.generate(z, spk, seed=13)
@@ -58,3 +58,18 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 32]:
         if abs(d).max() > 1e4:            # a stamp this configuration does not write (one slot per XCD: wave 1 only runs fc1)
             continue
         print(f"  {name:66s} {d.mean():6.2f} {d.min():6.2f} {d.max():6.2f}")
+    if "--workers" in sys.argv:
+        wb = (C.c_ulonglong * (6 * 32 * 128))()
+        if _lib.load().vqcpc_debug_xd_workers(wb) == 0:
+            wk = np.array(wb, dtype=np.int64).reshape(6, 32, 128)[:, :, 8:120] * 0.01
+            for e, nm in enumerate(["h_t published (service wave 0)", "past barrier A", "a_t published", "candidate of slot 0 published (chain wave 0)",
+                                    "x_t known", "past barrier B"]):
+                rel = wk[e] - wk[e].min(axis=0, keepdims=True)
+                print(f"  {nm}: every worker's mean lag behind the step's first worker, us; the last one lags {rel.max(axis=0).mean():.2f} on average")
+                print("    " + " ".join(f"{rel[r].mean():.2f}" for r in range(32)))
+            # the candidate exchange as the workers see it: last candidate published -> x_t known, per worker
+            last_c = wk[3].max(axis=0, keepdims=True)
+            d = wk[4] - last_c
+            print(f"  last worker's candidate published -> x_t known: mean over workers {d.mean():.2f}, slowest worker {d.mean(axis=1).max():.2f}, fastest {d.mean(axis=1).min():.2f}")
+            d = wk[1] - wk[0].max(axis=0, keepdims=True)
+            print(f"  last worker's h_t published -> past barrier A: mean over workers {d.mean():.2f}, slowest worker {d.mean(axis=1).max():.2f}")

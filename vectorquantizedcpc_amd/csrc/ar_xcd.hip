@@ -47,8 +47,16 @@ __device__ unsigned long long g_xd_stamps[128 * 16];
 extern "C" int vqcpc_debug_xd_stamps(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xd_stamps), sizeof(g_xd_stamps)) == hipSuccess ? 0 : -1;
 }
+// per-worker stamps of XCD 0 (slot 0's events on every worker): [event][worker][step 256..383]
+__device__ unsigned long long g_xd_workers[6 * 32 * 128];
+#define XD_WSTAMP(ev) do { if (xcc == 0 && lane == 0 && t >= 256 && t < 384) \
+        g_xd_workers[((ev) * 32 + rank) * 128 + (t - 256)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int vqcpc_debug_xd_workers(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xd_workers), sizeof(g_xd_workers)) == hipSuccess ? 0 : -1;
+}
 #else
 #define XD_STAMP(wv, i) do { } while (0)
+#define XD_WSTAMP(ev) do { } while (0)
 #endif
 
 #include "ar_chain.h"
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
                     if (lane == 0 && !drop)
                         xd_put(gc, ((unsigned)cw * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
-                    XD_STAMP(2, 9);
+                    XD_STAMP(2, 9); if (cw == 0) XD_WSTAMP(3);
                 }
             }
             XD_STAMP(2, 6);
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 }
                 if (cu < UPB) xd_put(gh, (((unsigned)(rank * BXT + cb) << 5) + cu) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
             }
-            XD_STAMP(0, 2);
+            XD_STAMP(0, 2); if (wave == 0) XD_WSTAMP(0);
             // ---- in the shadow of the h_t exchange: the sample x_{t-1} goes out (network_vocoder.py:78 output), the slot's state
             // and the noise for step t + 1, the first phase of the fc1 weights
             if (st_emit && cu == 0 && rank == (cb & 31)) {
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             XD_STAMP(0, 3);
             ps_barrier();                                                // A: h_t in LDS
             if (*s_abort) break;
-            XD_STAMP(0, 4);
+            XD_STAMP(0, 4); if (wave == 0) XD_WSTAMP(1);
             // ---- fc1 of the own slots (both together: every weight is used for both and then dropped); one slot per XCD: wave 1
             if (BXT > 1 && n_own > 0) {
                 float accA, accB;
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     if (sum_lane) xd_put(ga, (((unsigned)(rank * BXT + sv + 2) << 3) + r8) * 8u, ((u64)tag << 32) | __float_as_uint(v2), agent);
                 }
             }
-            XD_STAMP(0, 5);
+            XD_STAMP(0, 5); if (wave == 0) XD_WSTAMP(2);
             XD_STAMP(1, 10);
             __builtin_amdgcn_s_setprio(1);
             // ---- W_hh rows 80..83 of the OTHER wave's slots, behind the a_t exchange and the chain waves' fc2: one chain pass,
@@ -477,11 +485,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 const int x0 = __builtin_amdgcn_readlane(cls, f0 < 0 ? 0 : f0), x1 = __builtin_amdgcn_readlane(cls, 32 + (f1 < 0 ? 0 : f1));
                 x = lane < 32 ? x0 : x1;
             }
-            XD_STAMP(0, 1);
+            XD_STAMP(0, 1); if (wave == 0) XD_WSTAMP(4);
             __builtin_amdgcn_s_setprio(0);
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
             if (*s_abort) break;
-            XD_STAMP(0, 12);
+            XD_STAMP(0, 12); if (wave == 0) XD_WSTAMP(5);
         }
         // ---- the last step's x has nowhere to go: every utterance ended at least one step before n_steps
     }
