@@ -20,6 +20,9 @@ sys.path.insert(0, ROOT)
 from vectorquantizedcpc_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = os.path.join(ROOT, "build", "stamps", "libvqcpc_hip.so")
+for a in sys.argv[1:]:
+    if a.startswith("--lib="):        # e.g. the stamped build with the exchange waits ablated (-DXD_ABLATE=7)
+        _lib.LIB_PATH = os.path.abspath(a[6:])
 import vectorquantizedcpc_amd as V  # noqa: E402
 from vectorquantizedcpc_amd import synth  # noqa: E402
 
@@ -48,7 +51,8 @@ for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 16, 32]:
         ("chain wave 0: barrier A -> a_t of its slot gathered (after its first W_hh chains)", a[:, 8] - a[:, 4]),
         ("chain wave 0: a_t gathered -> candidate published (fc2 + draw)", a[:, 9] - a[:, 8]),
         ("chain wave 0: candidate published -> all its W_hh chains done", a[:, 6] - a[:, 9]),
-        ("service wave 0: W_hh rows done -> x_t known (candidate sweep + argmax)", a[:, 1] - a[:, 7]),
+        ("service wave 0: W_hh rows done -> noise of the next step drawn", a[:, 13] - a[:, 7]),
+        ("service wave 0: noise drawn -> x_t known (candidate sweep + argmax)", a[:, 1] - a[:, 13]),
         ("service wave 0: x_t known -> past barrier B", a[:, 12] - a[:, 1]),
         ("whole step", b[:, 0] - a[:, 0]),
     ]

@@ -58,11 +58,35 @@ extern "C" int vqcpc_debug_xd_workers(unsigned long long *out) {
 #define XD_STAMP(wv, i) do { } while (0)
 #define XD_WSTAMP(ev) do { } while (0)
 #endif
+// -DVQCPC_XD_BARS (alone: the stamps above perturb what these measure)
+#ifdef VQCPC_XD_BARS
+// every wave of worker 5 of XCD 0 at the two barriers of a step: [step 256..383][wave][arrives at A, leaves A, arrives at B, leaves B]
+__device__ unsigned long long g_xd_bars[128 * 12 * 4];
+// (the arrival time waits in a register and is stored behind the barrier: a store in front of it would be waited for by the
+// barrier's release fence, and the barrier would look as long as a store takes)
+#define XD_BARRIVE() do { xd_arrived = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define XD_BLEAVE(i) do { if (rank == 5 && xcc == 0 && lane == 0 && t >= 256 && t < 384) { \
+        g_xd_bars[((t - 256) * 12 + wave) * 4 + (i)] = xd_arrived; \
+        g_xd_bars[((t - 256) * 12 + wave) * 4 + (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xd_bars), sizeof(g_xd_bars)) == hipSuccess ? 0 : -1;
+}
+#else
+#define XD_BARRIVE() do { } while (0)
+#define XD_BLEAVE(i) do { } while (0)
+#endif
 
 #include "ar_chain.h"
 
-namespace {
+// Ablation of the exchange WAITS, for timing only (results are garbage: stale granules are used as they are found): bit 0 the
+// candidate poll, bit 1 the a_t poll, bit 2 the h_t sweep take whatever their first load returns.  What a step still costs then
+// is what the workgroup's own instruction streams, LDS traffic, L2 round trips and barriers cost -- profiles/r04_ablation.txt.
+// Never set in the shipped library (tools/build_stamps.sh "-DVQCPC_XD_STAMPS -DXD_ABLATE=7").
+#ifndef XD_ABLATE
+#define XD_ABLATE 0
+#endif
 
+namespace {
 
 // LDS carve, in floats (ints behind them)
 template <int BXT> struct Lds {
@@ -166,6 +190,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     __syncthreads();
 
     Waiter wt{p.status, p.timeout_ticks, 0};
+#ifdef VQCPC_XD_BARS
+    unsigned long long xd_arrived = 0;
+#endif
     int *s_abort = s_ctl + 3;
 
     // h_t gather: every thread takes column tid of every slot, the first 128 threads also column 768 + tid
@@ -184,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v2[b] >> 32) == tag;  \
             } else gran_load<BXT, 256>(v1, gh, hoff1);                                                            \
             _Pragma("unroll") for (int b = 0; b < BXT; ++b) ok &= b >= bx || (unsigned)(v1[b] >> 32) == tag;      \
-            if (__all(ok)) break;                                                                                 \
+            if ((XD_ABLATE & 4) || __all(ok)) break;                                                         \
             if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }                                                 \
             __builtin_amdgcn_s_sleep(1);                                                                          \
         }                                                                                                         \
@@ -209,14 +236,18 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             for (int t = 0; t < n_steps; ++t) {
                 const unsigned tag = (unsigned)t + 1u;
                 XD_SWEEP_H();
+                XD_BARRIVE();
                 ps_barrier();                                            // A: h_t in LDS
+                XD_BLEAVE(0);
                 if (*s_abort) break;
                 float v = chain_combine(chain_regs<NT_H>(w1, opnd));
                 v += b1;
                 v = v > 0.f ? v : 0.f;
                 if (sum_lane) xd_put(ga, (((unsigned)(rank * BXT) << 3) + r8) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
                 XD_STAMP(1, 10);
+                XD_BARRIVE();
                 ps_barrier();                                            // B
+                XD_BLEAVE(2);
                 if (*s_abort) break;
             }
         }
@@ -240,7 +271,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
             XD_SWEEP_H();
+            XD_BARRIVE();
             ps_barrier();                                                // A: h_t in LDS
+            XD_BLEAVE(0);
             if (*s_abort) break;
             for (int b = 0; b < bx; ++b) {
                 const float acc = chain_regs<NT_H>(w, opnd + b * HR);
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                         bool ok = true;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ok &= (unsigned)(va[i] >> 32) == tag;
-                        if (__all(ok)) break;
+                        if ((XD_ABLATE & 2) || __all(ok)) break;
                         if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
                     }
 #pragma unroll
@@ -300,7 +333,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 }
             }
             XD_STAMP(2, 6);
+            XD_BARRIVE();
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
+            XD_BLEAVE(2);
             if (*s_abort) break;
         }
     } else {
@@ -424,7 +459,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             for (int i = 0; i < 8; ++i) w1p[i] = wp1[64 * i];
             XD_SWEEP_H();
             XD_STAMP(0, 3);
+            XD_BARRIVE();
             ps_barrier();                                                // A: h_t in LDS
+            XD_BLEAVE(0);
             if (*s_abort) break;
             XD_STAMP(0, 4); if (wave == 0) XD_WSTAMP(1);
             // ---- fc1 of the own slots (both together: every weight is used for both and then dropped); one slot per XCD: wave 1
@@ -459,6 +496,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             XD_STAMP(0, 7);
             XD_STAMP(1, 11);
             draw_noise(t + 1);                                           // idle time: the candidates are still on their way
+            XD_STAMP(0, 13);
             // ---- x_t: the slot's 32 candidates (tag t + 1, from the chain waves' fc2), picked up BEFORE barrier B
             __builtin_amdgcn_s_setprio(3);
             if (n_own > 0) {
@@ -466,7 +504,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 wt.start();
                 for (unsigned spins = 0;; ++spins) {
                     g = ps_load(csrc);
-                    if (__all(!cell_on || (unsigned)(g >> 40) == tag)) break;
+                    if ((XD_ABLATE & 1) || __all(!cell_on || (unsigned)(g >> 40) == tag)) break;
                     if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
                 }
                 // first argmax per half of 32 lanes (classes ascend with the rank): order-preserving integer image of the score
@@ -488,7 +526,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             XD_STAMP(0, 1); if (wave == 0) XD_WSTAMP(4);
             __builtin_amdgcn_s_setprio(0);
+            XD_BARRIVE();
             ps_barrier();                                                // B: gsum of step t complete; hc free for h_{t+1}
+            XD_BLEAVE(2);
             if (*s_abort) break;
             XD_STAMP(0, 12); if (wave == 0) XD_WSTAMP(5);
         }
