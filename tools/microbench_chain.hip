@@ -3,6 +3,8 @@
 // at 1 / 2 / 3 waves per SIMD on every CU -- what a pass costs a wave when it shares its SIMD, with nothing else going on.
 //   variant 0: the decoder's pass (one accumulator, slot after slot)
 //   variant 1: two slots per pass, their phases interleaved (two accumulators)
+//   variant 2: the four slots at once on the matrix pipe: 112 dependent v_mfma_f32_4x4x1_16B_f32 (block = quad: A = the quad's four rows,
+//              B = the four slots; lane 4 b + j reads slot j's 112 operands itself: 28 ds_read_b128), four combines
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I vectorquantizedcpc_amd/csrc -o /tmp/mb_chain tools/microbench_chain.hip && /tmp/mb_chain
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -37,12 +39,31 @@ __device__ __forceinline__ void chain_regs2(const float *w, const float *opA, co
     }
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int MS = 136, MHS = 1092;          // chain stride / slot stride of the MFMA variant's operand copy: lane (kw, j) starts at bank 16 kw + 4 j
+__device__ __forceinline__ v4f chain_mfma(const float *w, const float *op) {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    float4 cur[2], nxt[2];
+    cur[0] = *(const float4 *)op; cur[1] = *(const float4 *)(op + 4);
+#pragma unroll
+    for (int g = 0; g < 14; ++g) {                                // 14 groups of 8 terms, the next group's operands requested first
+        if (g + 1 < 14) { nxt[0] = *(const float4 *)(op + 8 * (g + 1)); nxt[1] = *(const float4 *)(op + 8 * (g + 1) + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[8 * g + i], hv[i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+    }
+    return acc;
+}
+
 template <int VAR>
 __global__ void __launch_bounds__(768) k(const float *in, float *out, int rounds, unsigned long long *ticks) {
-    __shared__ float hc[4 * HR];
+    __shared__ float hc[4 * MHS];
     __shared__ float gsum[4 * 96];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (unsigned i = tid; i < 4 * HR; i += blockDim.x) hc[i] = in[i];
+    for (unsigned i = tid; i < 4 * MHS; i += blockDim.x) hc[i] = in[i & 4095];
     float w[NT_H];
 #pragma unroll
     for (int i = 0; i < NT_H; ++i) w[i] = in[4096 + ((tid * 7 + i) & 4095)];
@@ -57,6 +78,13 @@ __global__ void __launch_bounds__(768) k(const float *in, float *out, int rounds
                 const float acc = chain_regs<NT_H>(w, opnd + b * HR);
                 const float v = chain_combine(acc);
                 if (sum_lane) gsum[b * 96 + 8 * (wave % 12) + (lane >> 4) * 2 + (lane & 1u)] = v;
+            }
+        } else if (VAR == 2) {
+            const v4f a4 = chain_mfma(w, hc + j * MHS + cid * MS);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = chain_combine(a4[i]);
+                if (sum_lane) gsum[j * 96 + 8 * (wave % 12) + (lane >> 5) * 4 + i] = v;      // rows 4 rq + i of slot j (either c0 lane row holds it)
             }
         } else {
             for (int b = 0; b < 4; b += 2) {
@@ -81,12 +109,13 @@ int main() {
     const int rounds = 2000;
     static unsigned long long h[256 * 12];
     printf("variant,waves_per_simd,us_per_pass_of_one_slot_mean,slowest_wave,fastest_wave\n");
-    for (int var = 0; var < 2; ++var)
+    for (int var = 0; var < 3; ++var)
         for (int thr = 256; thr <= 768; thr += 256) {
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipMemset(ticks, 0, 256 * 12 * 8));
                 if (var == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(thr), 0, 0, in, out, rounds, ticks);
-                else hipLaunchKernelGGL(k<1>, dim3(256), dim3(thr), 0, 0, in, out, rounds, ticks);
+                else if (var == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(thr), 0, 0, in, out, rounds, ticks);
+                else hipLaunchKernelGGL(k<2>, dim3(256), dim3(thr), 0, 0, in, out, rounds, ticks);
                 CK(hipDeviceSynchronize());
             }
             CK(hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost));

@@ -234,4 +234,69 @@ __device__ __forceinline__ int chain_pos(int k, int stride) {
     return (2 * kw + c0) * stride + phase_pos_t<8 * NS>(8 * s + 4 * ci + q);
 }
 
+// ---- the same chains on the matrix pipe, for the FOUR slots of an XCD at once (ar_xcd_kernel<4>).  v_mfma_f32_4x4x1_16B_f32 is
+// sixteen independent 4x4 outer products, one per quad: lane 4 b + i supplies A_b[i], lane 4 b + j supplies B_b[j], and
+// D_b[i][j] += A_b[i] * B_b[j] (one rounding: bit for bit fmaf -- tools/microbench_mfma4x4.hip) lands in register i of lane
+// 4 b + j.  With the chain waves' lane layout (quad = chain (kw, c0) of rows 4 rq + 0..3) A is the lane's pinned weight of term
+// n -- exactly what v_fmac_f32_dpp used -- and B is term n's operand of slot j = lane & 3: one instruction advances the chains of
+// 4 rows x 4 slots, where the vector ALU needed 4 (one per slot).  Why: with three waves per SIMD a wave's 112-term dpp chain
+// costs the SIMD 0.27 us whoever waits for it (tools/microbench_chain.hip: 0.80 us per pass for the last of three waves), the
+// twelve passes of a 4-slot step 3.3 us -- the step was vector-ALU bound behind barrier A (tools/xcd_barriers.py: the youngest
+// wave of every SIMD reaches barrier B 3.6 us after A, with or without the exchange waits); the matrix pipe does the four
+// slots' chains of three waves in 1.5 us and leaves the vector ALU to the serial work.
+// Operands: the lane reads ITS slot's copy of the chain itself, terms in plain order (28 ds_read_b128 per step -- as many as the
+// dpp form's 4 x 7): hc[j * HS4 + cid * NT_H + n].  Slot stride HS4 = HR + 4: the four lanes of a quad start one 16-byte unit
+// apart, the four quads of a ds_read_b128 lane group (chains {0,6,3,5} or {2,4,1,7}, 28 units apart) 4 units apart -- 64 banks.
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int HS4 = HR + 4;
+constexpr int NG_H = NT_H / 8;         // groups of 8 terms (two 16-byte operand words)
+template <int NS>
+__device__ __forceinline__ int chain_pos_plain(int k, int stride) {
+    const int S = k >> 4, kw = S / NS, s = S - kw * NS;
+    const int q = (k >> 2) & 3, c0 = k & 1, ci = (k >> 1) & 1;
+    return (2 * kw + c0) * stride + 8 * s + 4 * ci + q;
+}
+// groups [G0, G1) of the chain, weights pinned (w[n] = term n); cur = the operands of group G0, already requested (it leaves
+// with those of group G1: a chain can pause between two calls without losing its prefetch)
+template <int G0, int G1>
+__device__ __forceinline__ void chain_mfma_regs(v4f &acc, const float *w, const float *op, float4 (&cur)[2]) {
+    float4 nxt[2];
+#pragma unroll
+    for (int g = G0; g < G1; ++g) {
+        nxt[0] = cur[0]; nxt[1] = cur[1];
+        if (g + 1 < NG_H) { nxt[0] = *(const float4 *)(op + 8 * (g + 1)); nxt[1] = *(const float4 *)(op + 8 * (g + 1) + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[8 * g + i], hv[i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+    }
+}
+// the whole chain with its weights streamed from the word-interleaved LDS copy (word i of the lane's chain at wp[i * WS]), a group
+// ahead of their use; w0 = words 0 and 1, requested before the barrier the chain waits behind
+template <int WS>
+__device__ __forceinline__ v4f chain_mfma_lds(const float4 *wp, const float4 (&w0)[2], const float *op) {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    float4 cur[2], nxt[2], wc[2], wn[2];
+    cur[0] = *(const float4 *)op; cur[1] = *(const float4 *)(op + 4);
+    wc[0] = w0[0]; wc[1] = w0[1];
+#pragma unroll
+    for (int g = 0; g < NG_H; ++g) {
+        nxt[0] = cur[0]; nxt[1] = cur[1]; wn[0] = wc[0]; wn[1] = wc[1];
+        if (g + 1 < NG_H) {
+            nxt[0] = *(const float4 *)(op + 8 * (g + 1)); nxt[1] = *(const float4 *)(op + 8 * (g + 1) + 4);
+            wn[0] = wp[(2 * (g + 1)) * WS]; wn[1] = wp[(2 * (g + 1) + 1) * WS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+        const float wv[8] = {wc[0].x, wc[0].y, wc[0].z, wc[0].w, wc[1].x, wc[1].y, wc[1].z, wc[1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[i], hv[i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur[0] = nxt[0]; cur[1] = nxt[1]; wc[0] = wn[0]; wc[1] = wn[1];
+    }
+    return acc;
+}
+
 }  // namespace

@@ -85,6 +85,10 @@ extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
 #ifndef XD_ABLATE
 #define XD_ABLATE 0
 #endif
+// four slots per XCD: groups of 8 terms (of 14) a chain wave runs before it turns to fc2 of its slot
+#ifndef XD_GSPLIT
+#define XD_GSPLIT 10
+#endif
 
 namespace {
 
@@ -94,17 +98,15 @@ template <int BXT> struct Lds {
     static constexpr int fc1w = gemb + NC * ROWS;         // [28 words][64 lane-chains (row r8, chain cid)][4]: word-interleaved (chain_lds2)
     static constexpr int fc2w = fc1w + FPB * HR;          // [8 words][64 lane-chains][4]
     static constexpr int whx = fc2w + FPB * HF;           // [28 words][32 lane-chains][4]  W_hh rows 80..83 (the chain waves hold rows 0..79)
-    static constexpr int hc = whx + 4 * HR;               // [BXT][HR]  h_t, chain order
-    static constexpr int ac = hc + BXT * HR;              // [BXT][8 chains][AS]  a_t (32 terms per chain, chain stride AS = 48: bank windows)
+    static constexpr int HS = BXT == 4 ? HS4 : HR;        // slot stride of h_t (four slots: the matrix-pipe chains' copy, ar_chain.h)
+    static constexpr int hc = whx + 4 * HR;               // [BXT][HS]  h_t, chain by chain (dpp chains: phase order; matrix pipe: term order)
+    static constexpr int ac = hc + BXT * HS;              // [BXT][8 chains][AS]  a_t (32 terms per chain, chain stride AS = 48: bank windows)
     static constexpr int gsum = ac + BXT * 8 * 48;            // [BXT][96]  W_hh h of the owned rows [gate][unit]
     static constexpr int noise = gsum + BXT * 96;         // [2][BXT][8] Gumbel noise of the step in flight / the next one
     static constexpr int mtab = noise + 2 * BXT * 8;      // [NC] mu-law decode table
     static constexpr int bq = mtab + NC;                  // [3][32] b_hh of the owned units
-    static constexpr int hold = bq + 96;                  // [BXT][32] h_{t-1} of the owned units
-    static constexpr int gcq = hold + BXT * 32;           // [BXT][3][32] conditioning row in use
-    static constexpr int seg = gcq + BXT * 96;            // int [BXT][8] {index, row, t0, len, utt}
-    static constexpr int sinfo = seg + BXT * 8;           // int [BXT][4] {lt, utt, active} of the step in flight
-    static constexpr int ctl = sinfo + BXT * 4;           // int [8] {xcc, rank, ok, abort, the call's status tag}
+    static constexpr int seg = bq + 96;                   // int [BXT][8] {index, row, t0, len, utt, samples into / index of the conditioning frame, first Gcond row}
+    static constexpr int ctl = seg + BXT * 8;             // int [8] {xcc, rank, ok, abort, the call's status tag}
     static constexpr int total = ctl + 8;
 };
 
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     using L = Lds<BXT>;
     float *gemb = smem + L::gemb, *fc1w = smem + L::fc1w, *fc2w = smem + L::fc2w, *whx = smem + L::whx, *hc = smem + L::hc,
           *ac = smem + L::ac, *gsum = smem + L::gsum;
-    float *noise = smem + L::noise, *mtab = smem + L::mtab, *c_bq = smem + L::bq, *c_hold = smem + L::hold, *c_gc = smem + L::gcq;
-    int *seg_st = (int *)(smem + L::seg), *sinfo = (int *)(smem + L::sinfo), *s_ctl = (int *)(smem + L::ctl);
+    float *noise = smem + L::noise, *mtab = smem + L::mtab, *c_bq = smem + L::bq;
+    int *seg_st = (int *)(smem + L::seg), *s_ctl = (int *)(smem + L::ctl);
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -178,14 +180,12 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     }
     for (unsigned e = tid; e < NC; e += THREADS) mtab[e] = p.mulaw_tab[e];
     for (unsigned e = tid; e < 96; e += THREADS) { const unsigned g = e >> 5, u = e & 31; c_bq[e] = u < UPB ? p.b_hh[g * HR + UPB * rank + u] : 0.f; }
-    for (unsigned e = tid; e < BXT * 32; e += THREADS) c_hold[e] = 0.f;
-    for (unsigned e = tid; e < BXT * 96; e += THREADS) { c_gc[e] = 0.f; gsum[e] = 0.f; }
+    for (unsigned e = tid; e < BXT * 96; e += THREADS) gsum[e] = 0.f;
     for (unsigned e = tid; e < BXT; e += THREADS) {
         const XdSeg sg = (int)e < bx ? p.segs[(size_t)(xcc + 8 * e) * p.max_seg] : XdSeg{-1, 0, 0, 0u};
         seg_st[e * 8 + 0] = 0; seg_st[e * 8 + 1] = sg.len > 0 ? sg.row : -1; seg_st[e * 8 + 2] = sg.t0; seg_st[e * 8 + 3] = sg.len;
         seg_st[e * 8 + 4] = (int)sg.utt; seg_st[e * 8 + 5] = 0; seg_st[e * 8 + 6] = 0;      // samples into / index of the conditioning frame
         seg_st[e * 8 + 7] = sg.len > 0 ? ((const int *)(p.segs + (size_t)8 * BXT * p.max_seg))[sg.row] : 0;      // the utterance's first Gcond row
-        sinfo[e * 4 + 0] = 0; sinfo[e * 4 + 1] = 0; sinfo[e * 4 + 2] = 0;
     }
     __syncthreads();
 
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     // h_t gather: every thread takes column tid of every slot, the first 128 threads also column 768 + tid
     const unsigned hk1 = tid, hk2 = THREADS + (tid & 127u);
     const unsigned hoff1 = ((((hk1 / UPB) * BXT) << 5) + hk1 % UPB) * 8u, hoff2 = ((((hk2 / UPB) * BXT) << 5) + hk2 % UPB) * 8u;
-    const unsigned hdst1 = chain_pos<HR / 64>(hk1, NT_H), hdst2 = chain_pos<HR / 64>(hk2, NT_H);
+    const unsigned hdst1 = BXT == 4 ? chain_pos_plain<HR / 64>(hk1, NT_H) : chain_pos<HR / 64>(hk1, NT_H),
+                   hdst2 = BXT == 4 ? chain_pos_plain<HR / 64>(hk2, NT_H) : chain_pos<HR / 64>(hk2, NT_H);
     const bool two = tid < HR - THREADS;
 #define XD_SWEEP_H()                                                                                              \
     do {                                                                                                          \
@@ -216,11 +217,12 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             __builtin_amdgcn_s_sleep(1);                                                                          \
         }                                                                                                         \
         _Pragma("unroll") for (int b = 0; b < BXT; ++b) {                                                         \
-            if (b < bx) { hc[b * HR + hdst1] = __uint_as_float((unsigned)v1[b]); if (two) hc[b * HR + hdst2] = __uint_as_float((unsigned)v2[b]); } \
+            if (b < bx) { hc[b * L::HS + hdst1] = __uint_as_float((unsigned)v1[b]); if (two) hc[b * L::HS + hdst2] = __uint_as_float((unsigned)v2[b]); } \
         }                                                                                                         \
     } while (0)
 
-    const float *opnd = hc + cid * NT_H + 4 * j;
+    const float *opnd = hc + cid * NT_H + 4 * j;                       // dpp chains: the quad's lane j reads word j of a phase
+    const float *opm = hc + j * L::HS + cid * NT_H;                     // matrix-pipe chains (four slots): lane j reads slot j's chain
     bool fc1_role = false;
     if constexpr (BXT == 1) fc1_role = wave == 1;
     if (fc1_role) {
@@ -275,61 +277,78 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             ps_barrier();                                                // A: h_t in LDS
             XD_BLEAVE(0);
             if (*s_abort) break;
-            for (int b = 0; b < bx; ++b) {
-                const float acc = chain_regs<NT_H>(w, opnd + b * HR);
-                const float v = chain_combine(acc);
-                if (sum_lane) gsum[b * 96 + row_local] = v;
-                if (fc2_wave && b + 1 == fc2_after) {
-                    // ---- a_t of slot `wave` (256 granules, 4 per lane) -> fc2 -> Gumbel-max candidate of the 8 owned classes
-                    const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
-                    const unsigned adst = (unsigned)chain_pos<HF / 64>((int)lane, 48);      // a_t[lane + 64 i]: chain 2 i + (lane & 1), i.e. 96 i further
-                    float4 wa = wp2[0], wb = wp2[64];                    // first weights and the noise: on their way during the sweep
-                    unsigned lno = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id, from the hardware
-                    asm volatile("" : "+v"(lno));      // opaque, and rebuilt: the hoisted address of this read -- then r8, then the lane id
-                    const unsigned r8o = ((lno >> 5) << 2) | (lno & 3u);      // itself -- was spilled to scratch and reloaded at every step
-                    const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8o];
-                    u64 va[4];
-                    wt.start();
-                    for (unsigned spins = 0;; ++spins) {
-                        gran_load4b<512 * BXT>(va, ga, ga + 128 * BXT, aoff);
-                        bool ok = true;
+            auto fc2_and_draw = [&]() {
+                // ---- a_t of slot `wave` (256 granules, 4 per lane) -> fc2 -> Gumbel-max candidate of the 8 owned classes
+                const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
+                const unsigned adst = (unsigned)chain_pos<HF / 64>((int)lane, 48);      // a_t[lane + 64 i]: chain 2 i + (lane & 1), i.e. 96 i further
+                float4 wa = wp2[0], wb = wp2[64];                    // first weights and the noise: on their way during the sweep
+                unsigned lno = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id, from the hardware
+                asm volatile("" : "+v"(lno));      // opaque, and rebuilt: the hoisted address of this read -- then r8, then the lane id
+                const unsigned r8o = ((lno >> 5) << 2) | (lno & 3u);      // itself -- was spilled to scratch and reloaded at every step
+                const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8o];
+                u64 va[4];
+                wt.start();
+                for (unsigned spins = 0;; ++spins) {
+                    gran_load4b<512 * BXT>(va, ga, ga + 128 * BXT, aoff);
+                    bool ok = true;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) ok &= (unsigned)(va[i] >> 32) == tag;
-                        if ((XD_ABLATE & 2) || __all(ok)) break;
-                        if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
-                    }
+                    for (int i = 0; i < 4; ++i) ok &= (unsigned)(va[i] >> 32) == tag;
+                    if ((XD_ABLATE & 2) || __all(ok)) break;
+                    if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
+                }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ac[cw * (8 * 48) + 96 * i + adst] = __uint_as_float((unsigned)va[i]);
-                    XD_STAMP(2, 8);
-                    const float4 a0 = *(const float4 *)opnd2, a1 = *(const float4 *)(opnd2 + 16);
-                    const float hv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    float acc2 = 0.f;
+                for (int i = 0; i < 4; ++i) ac[cw * (8 * 48) + 96 * i + adst] = __uint_as_float((unsigned)va[i]);
+                XD_STAMP(2, 8);
+                const float4 a0 = *(const float4 *)opnd2, a1 = *(const float4 *)(opnd2 + 16);
+                const float hv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                float acc2 = 0.f;
 #pragma unroll
-                    for (int J = 0; J < 4; ++J) {                            // 32 terms: 8 per quad lane, weights two 16-byte words at a time
-                        float4 na = wa, nb2 = wb;
-                        if (J < 3) { na = wp2[64 * (2 * J + 2)]; nb2 = wp2[64 * (2 * J + 3)]; }
-                        const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-                        if (J == 0) fmac8<0>(acc2, hv, w8);
-                        if (J == 1) fmac8<1>(acc2, hv, w8);
-                        if (J == 2) fmac8<2>(acc2, hv, w8);
-                        if (J == 3) fmac8<3>(acc2, hv, w8);
-                        wa = na; wb = nb2;
-                    }
-                    float v2 = chain_combine(acc2);
-                    v2 += b2;
-                    const float sc = v2 + nz;                                // classes 0..3 of the 8 in lanes 0..3, 4..7 in lanes 32..35
-                    float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 0));
-                    int kb = 0;
+                for (int J = 0; J < 4; ++J) {                            // 32 terms: 8 per quad lane, weights two 16-byte words at a time
+                    float4 na = wa, nb2 = wb;
+                    if (J < 3) { na = wp2[64 * (2 * J + 2)]; nb2 = wp2[64 * (2 * J + 3)]; }
+                    const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                    if (J == 0) fmac8<0>(acc2, hv, w8);
+                    if (J == 1) fmac8<1>(acc2, hv, w8);
+                    if (J == 2) fmac8<2>(acc2, hv, w8);
+                    if (J == 3) fmac8<3>(acc2, hv, w8);
+                    wa = na; wb = nb2;
+                }
+                float v2 = chain_combine(acc2);
+                v2 += b2;
+                const float sc = v2 + nz;                                // classes 0..3 of the 8 in lanes 0..3, 4..7 in lanes 32..35
+                float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 0));
+                int kb = 0;
 #pragma unroll
-                    for (int k = 1; k < 8; ++k) {
-                        const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), k < 4 ? k : 28 + k));
-                        if (sk > best) { best = sk; kb = k; }
-                    }
-                    const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
-                    if (lane == 0 && !drop)
-                        xd_put(gc, ((unsigned)cw * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chain wave has slack here; draining its store now measured 0.035 us/step (profiles/r04_ab_*, section 5)
-                    XD_STAMP(2, 9); if (cw == 0) XD_WSTAMP(3);
+                for (int k = 1; k < 8; ++k) {
+                    const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), k < 4 ? k : 28 + k));
+                    if (sk > best) { best = sk; kb = k; }
+                }
+                const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
+                if (lane == 0 && !drop)
+                    xd_put(gc, ((unsigned)cw * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chain wave has slack here; draining its store now measured 0.035 us/step (profiles/r04_ab_*, section 5)
+                XD_STAMP(2, 9); if (cw == 0) XD_WSTAMP(3);
+            };
+            if constexpr (BXT == 4) {
+                // ---- the four slots at once on the matrix pipe (ar_chain.h); the wave of slot cw looks for a_t after XD_GSPLIT of the
+                // chain's 14 groups: fc1 is out about then
+                v4f a4 = {0.f, 0.f, 0.f, 0.f};
+                float4 cur[2];
+                cur[0] = *(const float4 *)opm; cur[1] = *(const float4 *)(opm + 4);
+                chain_mfma_regs<0, XD_GSPLIT>(a4, w, opm, cur);
+                if (fc2_wave) fc2_and_draw();
+                chain_mfma_regs<XD_GSPLIT, NG_H>(a4, w, opm, cur);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = chain_combine(a4[i]);                // row 8 cw + 4 rq + i of slot j
+                    if (sum_lane) gsum[j * 96 + 8 * cw + 4 * rq + i] = v;
+                }
+            } else {
+                for (int b = 0; b < bx; ++b) {
+                    const float acc = chain_regs<NT_H>(w, opnd + b * HR);
+                    const float v = chain_combine(acc);
+                    if (sum_lane) gsum[b * 96 + row_local] = v;
+                    if (fc2_wave && b + 1 == fc2_after) fc2_and_draw();
                 }
             }
             XD_STAMP(2, 6);
@@ -351,6 +370,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         const int n_own = bx > sv ? (bx - sv + 1) / 2 : 0;              // slots sv, sv + 2 < bx
         const bool cell_on = cb < bx;
         const float b1 = p.b_fc1[FPB * rank + r8];
+        float b1q[4] = {0.f, 0.f, 0.f, 0.f};                              // four slots: the lane's accumulators are rows 4 rq + 0..3
+        if constexpr (BXT == 4) { for (int i = 0; i < 4; ++i) b1q[i] = p.b_fc1[FPB * rank + 4 * rq + i]; }
         const float4 *wp1 = (const float4 *)fc1w + lane;                   // word i of this lane's chain at wp1[64 i]
         const float4 *wpx = (const float4 *)whx + (lane & 31u);            // rows 80..83: both half waves read the same 32 lane-chains, word i at wpx[32 i]
         const float bq0 = c_bq[cu], bq1 = c_bq[32 + cu], bq2 = c_bq[64 + cu];
@@ -454,9 +475,13 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 if (p.mulaw) p.mulaw[(size_t)st_erow * p.Lout + st_eidx] = x;
             }
             advance(t + 1);
-            float4 w1p[8];
+            float4 w1p[8];                                               // the first weights of what follows barrier A, requested in front of it
+            if constexpr (BXT == 4) {
+                w1p[0] = sv == 0 ? wp1[0] : wpx[0]; w1p[1] = sv == 0 ? wp1[64] : wpx[32];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w1p[i] = wp1[64 * i];
+                for (int i = 0; i < 8; ++i) w1p[i] = wp1[64 * i];
+            }
             XD_SWEEP_H();
             XD_STAMP(0, 3);
             XD_BARRIVE();
@@ -465,7 +490,28 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             if (*s_abort) break;
             XD_STAMP(0, 4); if (wave == 0) XD_WSTAMP(1);
             // ---- fc1 of the own slots (both together: every weight is used for both and then dropped); one slot per XCD: wave 1
-            if (BXT > 1 && n_own > 0) {
+            if constexpr (BXT == 4) {
+                // ---- four slots: the matrix pipe takes them together (ar_chain.h), so the two waves split the ROWS instead of the slots:
+                // wave 0 fc1 (the step's critical path: a_t goes out first), wave 1 W_hh rows 80..83
+                const float4 wpre[2] = {w1p[0], w1p[1]};
+                if (sv == 0) {
+                    const v4f a4 = chain_mfma_lds<64>(wp1, wpre, opm);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = chain_combine(a4[i]);                  // fc1 row 4 rq + i of slot j
+                        v += b1q[i];
+                        v = v > 0.f ? v : 0.f;
+                        if (sum_lane && (int)j < bx) xd_put(ga, (((unsigned)(rank * BXT) + j) << 3) * 8u + (4u * rq + (unsigned)i) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
+                    }
+                } else {
+                    const v4f a4 = chain_mfma_lds<32>(wpx, wpre, opm);     // both half waves run the same 32 lane-chains; the lower half's results count
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = chain_combine(a4[i]);
+                        if (sum_lane && lane < 32) gsum[j * 96 + 80 + i] = v;
+                    }
+                }
+            } else if (BXT > 1 && n_own > 0) {
                 float accA, accB;
                 chain_lds2<NT_H, 64>(wp1, w1p, opnd + sv * HR, opnd + (sv + 2 < BXT ? sv + 2 : sv) * HR, n_own > 1, accA, accB);
                 float v = chain_combine(accA);
@@ -484,7 +530,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             __builtin_amdgcn_s_setprio(1);
             // ---- W_hh rows 80..83 of the OTHER wave's slots, behind the a_t exchange and the chain waves' fc2: one chain pass,
             // the lower half wave on slot 1 - sv, the upper half on slot 3 - sv
-            if (xb0 < bx) {
+            if (BXT != 4 && xb0 < bx) {
                 float4 wx0[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) wx0[i] = wpx[32 * i];
