@@ -44,6 +44,8 @@ for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 16, 32]:
         ("service wave 0: past barrier B -> own h_t published (gsum reads, cell update)", a[:, 2] - a[:, 0]),
         ("service wave 0: h published -> h_t of all 32 workers gathered (+ sample out, next state, noise)", a[:, 3] - a[:, 2]),
         ("barrier A", a[:, 4] - a[:, 3]),
+        ("service wave 0 (four slots): barrier A -> last term of the fc1 chain issued", a[:, 14] - a[:, 4]),
+        ("service wave 0 (four slots): barrier A -> result of the last term there", a[:, 15] - a[:, 4]),
         ("service wave 0: barrier A -> fc1 rows of its slots published", a[:, 5] - a[:, 4]),
         ("service wave 1: barrier A -> fc1 rows of its slots published", a[:, 10] - a[:, 4]),
         ("service wave 0: fc1 published -> W_hh rows 80..83 of the other wave's slots done", a[:, 7] - a[:, 5]),

@@ -218,9 +218,13 @@ __device__ __forceinline__ unsigned xd_lane_of(unsigned rr, unsigned cc) { retur
 
 // Row sum from the 8 chain lanes of a row: a0 + a1 across the two 16-lane rows of an rq pair (lane ^ 16), then
 // ((q0 + q1) + q2) + q3 along the K quarters (lane + 4, + 8, + 12 inside the row) -- the order of the MFMA kernels.
-// Meaningful in lanes with kw == 0 (either c0 row).
+// Meaningful in lanes with kw == 0 of the c0 = 0 rows (lanes 0..3 and 32..35: sum_lane).  The partner row comes through
+// v_permlane16_swap_b32 (gfx950: the second operand's rows 0 and 2 receive the first operand's rows 1 and 3), not ds_swizzle: a
+// swizzle is an LDS round trip, ~0.1 us behind the other waves' reads -- and four in a row, one per accumulator of a matrix-pipe
+// chain, were 0.4 us of the step's critical path (fc1 -> a_t).
 __device__ __forceinline__ float chain_combine(float acc) {
-    const float o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(acc), 0x401F));     // lane ^ 16
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+    const float o = __uint_as_float(sw[1]);                                                        // rows 0 and 2: lane + 16
     const float q = acc + o;
     const float q1 = PS_DPP(q, 0x104), q2 = PS_DPP(q, 0x108), q3 = PS_DPP(q, 0x10C);               // row_shl:4 / 8 / 12
     return ((q + q1) + q2) + q3;
@@ -273,28 +277,33 @@ __device__ __forceinline__ void chain_mfma_regs(v4f &acc, const float *w, const 
         cur[0] = nxt[0]; cur[1] = nxt[1];
     }
 }
-// the whole chain with its weights streamed from the word-interleaved LDS copy (word i of the lane's chain at wp[i * WS]), a group
-// ahead of their use; w0 = words 0 and 1, requested before the barrier the chain waits behind
-template <int WS>
-__device__ __forceinline__ v4f chain_mfma_lds(const float4 *wp, const float4 (&w0)[2], const float *op) {
+// the whole chain with its weights streamed from the word-interleaved LDS copy (word i of the lane's chain at wp[i * WS]), D groups
+// ahead of their use -- weights AND operands: behind barrier A a ds_read_b128 comes back after ~300 cycles (twelve waves read), a
+// group's 8 dependent matrix instructions take ~140, and with one group of prefetch the chain ran at the LDS latency (fc1, the first
+// thing on the step's critical path: 1.9 us; profiles/r04_mfma_chains.txt).  wpre = words 0 .. 2 D - 1, requested before the barrier
+// the chain waits behind.
+template <int WS, int D>
+__device__ __forceinline__ v4f chain_mfma_lds(const float4 *wp, const float4 *wpre, const float *op) {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
-    float4 cur[2], nxt[2], wc[2], wn[2];
-    cur[0] = *(const float4 *)op; cur[1] = *(const float4 *)(op + 4);
-    wc[0] = w0[0]; wc[1] = w0[1];
+    float4 hb[D][2], wb[D][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        hb[d][0] = *(const float4 *)(op + 8 * d); hb[d][1] = *(const float4 *)(op + 8 * d + 4);
+        wb[d][0] = wpre[2 * d]; wb[d][1] = wpre[2 * d + 1];
+    }
 #pragma unroll
     for (int g = 0; g < NG_H; ++g) {
-        nxt[0] = cur[0]; nxt[1] = cur[1]; wn[0] = wc[0]; wn[1] = wc[1];
-        if (g + 1 < NG_H) {
-            nxt[0] = *(const float4 *)(op + 8 * (g + 1)); nxt[1] = *(const float4 *)(op + 8 * (g + 1) + 4);
-            wn[0] = wp[(2 * (g + 1)) * WS]; wn[1] = wp[(2 * (g + 1) + 1) * WS];
-        }
+        const int s = g % D;
         __builtin_amdgcn_sched_barrier(0);
-        const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
-        const float wv[8] = {wc[0].x, wc[0].y, wc[0].z, wc[0].w, wc[1].x, wc[1].y, wc[1].z, wc[1].w};
+        const float hv[8] = {hb[s][0].x, hb[s][0].y, hb[s][0].z, hb[s][0].w, hb[s][1].x, hb[s][1].y, hb[s][1].z, hb[s][1].w};
+        const float wv[8] = {wb[s][0].x, wb[s][0].y, wb[s][0].z, wb[s][0].w, wb[s][1].x, wb[s][1].y, wb[s][1].z, wb[s][1].w};
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[i], hv[i], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        cur[0] = nxt[0]; cur[1] = nxt[1]; wc[0] = wn[0]; wc[1] = wn[1];
+        if (g + D < NG_H) {                                     // refill the buffer just used with group g + D
+            hb[s][0] = *(const float4 *)(op + 8 * (g + D)); hb[s][1] = *(const float4 *)(op + 8 * (g + D) + 4);
+            wb[s][0] = wp[(2 * (g + D)) * WS]; wb[s][1] = wp[(2 * (g + D) + 1) * WS];
+        }
     }
     return acc;
 }

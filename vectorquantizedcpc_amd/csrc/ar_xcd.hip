@@ -89,6 +89,16 @@ extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
 #ifndef XD_GSPLIT
 #define XD_GSPLIT 10
 #endif
+// four slots per XCD: groups of 8 terms the service waves' chains request ahead (weights and operands both come from LDS)
+#ifndef XD_DEPTH
+#define XD_DEPTH 3
+#endif
+#ifndef XD_NAP
+#define XD_NAP 42
+#endif
+#ifndef XD_HOLD
+#define XD_HOLD 0
+#endif
 
 namespace {
 
@@ -106,7 +116,8 @@ template <int BXT> struct Lds {
     static constexpr int mtab = noise + 2 * BXT * 8;      // [NC] mu-law decode table
     static constexpr int bq = mtab + NC;                  // [3][32] b_hh of the owned units
     static constexpr int seg = bq + 96;                   // int [BXT][8] {index, row, t0, len, utt, samples into / index of the conditioning frame, first Gcond row}
-    static constexpr int ctl = seg + BXT * 8;             // int [8] {xcc, rank, ok, abort, the call's status tag}
+    static constexpr int sinfo = seg + BXT * 8;           // int [BXT][2] {lt, utt} of the NEXT step, posted by advance() (four slots: chain wave 9 draws the noise)
+    static constexpr int ctl = sinfo + BXT * 2;           // int [8] {xcc, rank, ok, abort, the call's status tag}
     static constexpr int total = ctl + 8;
 };
 
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     float *gemb = smem + L::gemb, *fc1w = smem + L::fc1w, *fc2w = smem + L::fc2w, *whx = smem + L::whx, *hc = smem + L::hc,
           *ac = smem + L::ac, *gsum = smem + L::gsum;
     float *noise = smem + L::noise, *mtab = smem + L::mtab, *c_bq = smem + L::bq;
-    int *seg_st = (int *)(smem + L::seg), *s_ctl = (int *)(smem + L::ctl);
+    int *seg_st = (int *)(smem + L::seg), *sinfo = (int *)(smem + L::sinfo), *s_ctl = (int *)(smem + L::ctl);
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             for (int x = 0; x < 8; ++x)
                 if (__hip_atomic_load(ctl + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)NW) ok = 0;
         if (!ok) __hip_atomic_store(p.status, p.status_tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = (int)p.status_tag;
+        s_ctl[0] = (int)xid; s_ctl[1] = (int)r; s_ctl[2] = ok; s_ctl[3] = 0; s_ctl[4] = (int)p.status_tag; s_ctl[5] = 0;
     }
     __syncthreads();
     const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[0]), rank = __builtin_amdgcn_readfirstlane(s_ctl[1]);
@@ -264,11 +275,15 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
         }
         // wave b < bx also runs fc2 + the draw of slot b (one slot per wave, in parallel), between its W_hh chains: a_t of the
         // slot arrives while the first chains run
-        const bool fc2_wave = cw < bx;
+        // which slot's fc2 + draw this wave runs.  Four slots: waves 2, 3, 6, 7 (SIMDs 2 and 3) take slots 0..3 -- the chain waves that share
+        // a SIMD with a service wave stay pure chains (their matrix instructions starve the vector instructions of whoever shares the SIMD:
+        // profiles/r04_mfma_chains.txt), and wave 11 draws the next step's noise once its chain is through
+        const int fs = BXT == 4 ? ((cw & 2) == 0 && cw < 6 ? 2 * (cw >> 2) + (cw & 1) : BXT) : cw;
+        const bool fc2_wave = fs < bx;
         const int fc2_after = bx < 3 ? bx : 3;                             // chains done before it looks for a_t
         const float b2 = p.b_fc2[FPB * rank + r8];
         const float4 *wp2 = (const float4 *)fc2w + lane;                   // word i of this lane's chain at wp2[64 i]
-        const float *opnd2 = ac + cw * (8 * 48) + cid * 48 + 4 * j;
+        const float *opnd2 = ac + (fs < BXT ? fs : 0) * (8 * 48) + cid * 48 + 4 * j;
         ps_barrier();                                                      // state and noise of step 0 posted
         for (int t = 0; t < n_steps; ++t) {
             const unsigned tag = (unsigned)t + 1u;
@@ -279,13 +294,13 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             if (*s_abort) break;
             auto fc2_and_draw = [&]() {
                 // ---- a_t of slot `wave` (256 granules, 4 per lane) -> fc2 -> Gumbel-max candidate of the 8 owned classes
-                const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)cw) << 3) + (lane & 7u)) * 8u;
+                const unsigned aoff = (((((lane >> 3) * BXT) + (unsigned)fs) << 3) + (lane & 7u)) * 8u;
                 const unsigned adst = (unsigned)chain_pos<HF / 64>((int)lane, 48);      // a_t[lane + 64 i]: chain 2 i + (lane & 1), i.e. 96 i further
                 float4 wa = wp2[0], wb = wp2[64];                    // first weights and the noise: on their way during the sweep
                 unsigned lno = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id, from the hardware
                 asm volatile("" : "+v"(lno));      // opaque, and rebuilt: the hoisted address of this read -- then r8, then the lane id
                 const unsigned r8o = ((lno >> 5) << 2) | (lno & 3u);      // itself -- was spilled to scratch and reloaded at every step
-                const float nz = noise[(t & 1) * (BXT * 8) + cw * 8 + r8o];
+                const float nz = noise[(t & 1) * (BXT * 8) + fs * 8 + r8o];
                 u64 va[4];
                 wt.start();
                 for (unsigned spins = 0;; ++spins) {
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                     if (wt.expired(spins, lane, s_abort + 1)) { *s_abort = 1; break; }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ac[cw * (8 * 48) + 96 * i + adst] = __uint_as_float((unsigned)va[i]);
+                for (int i = 0; i < 4; ++i) ac[fs * (8 * 48) + 96 * i + adst] = __uint_as_float((unsigned)va[i]);
                 XD_STAMP(2, 8);
                 const float4 a0 = *(const float4 *)opnd2, a1 = *(const float4 *)(opnd2 + 16);
                 const float hv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -325,9 +340,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 }
                 const bool drop = p.dbg_drop_step >= 0 && t == p.dbg_drop_step && rank == 3 && xcc == 0;
                 if (lane == 0 && !drop)
-                    xd_put(gc, ((unsigned)cw * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
+                    xd_put(gc, ((unsigned)fs * NW + (unsigned)rank) * 8u, ((u64)((tag << 8) | (unsigned)(FPB * rank + kb)) << 32) | __float_as_uint(best), agent);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chain wave has slack here; draining its store now measured 0.035 us/step (profiles/r04_ab_*, section 5)
-                XD_STAMP(2, 9); if (cw == 0) XD_WSTAMP(3);
+                XD_STAMP(2, 9); if (fs == 0) XD_WSTAMP(3);
             };
             if constexpr (BXT == 4) {
                 // ---- the four slots at once on the matrix pipe (ar_chain.h); the wave of slot cw looks for a_t after XD_GSPLIT of the
@@ -335,6 +350,15 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 v4f a4 = {0.f, 0.f, 0.f, 0.f};
                 float4 cur[2];
                 cur[0] = *(const float4 *)opm; cur[1] = *(const float4 *)(opm + 4);
+                // waves 4 and 8 share fc1's SIMD (wave 0): they stand back until a_t is out.  Three dependent-chain waves keep a SIMD's issue port
+                // busy; fc1 -- the head of the step's critical path -- ran at a third of the matrix pipe, and the 60 vector instructions between its
+                // last term and the a_t stores took 0.4..0.7 us among the others' matrix instructions (profiles/r04_mfma_chains.txt)
+#if XD_HOLD
+                if ((wave & 3) == 0)
+                    while (__hip_atomic_load(s_ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tag) __builtin_amdgcn_s_sleep(2);
+#elif XD_NAP > 0
+                if ((wave & 3) == 0) __builtin_amdgcn_s_sleep(XD_NAP);
+#endif
                 chain_mfma_regs<0, XD_GSPLIT>(a4, w, opm, cur);
                 if (fc2_wave) fc2_and_draw();
                 chain_mfma_regs<XD_GSPLIT, NG_H>(a4, w, opm, cur);
@@ -342,6 +366,18 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 for (int i = 0; i < 4; ++i) {
                     const float v = chain_combine(a4[i]);                // row 8 cw + 4 rq + i of slot j
                     if (sum_lane) gsum[j * 96 + 8 * cw + 4 * rq + i] = v;
+                }
+                if (wave == 11) {
+                    // ---- the Gumbel noise of step t + 1's draw, all four slots (class lane & 7 of slot lane >> 3): it depends on nothing but the
+                    // slots' clocks, which advance() posted in front of barrier A
+                    unsigned ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    const int b = (int)(ln >> 3);
+                    if (ln < 32 && b < bx) {
+                        const unsigned cls = FPB * rank + (ln & 7u);
+                        const unsigned wd = philox_word((unsigned)sinfo[b * 2], (unsigned)sinfo[b * 2 + 1], cls >> 2, (unsigned)p.seed, (unsigned)(p.seed >> 32), (int)(cls & 3u));
+                        noise[((t + 1) & 1) * (BXT * 8) + b * 8 + (ln & 7u)] = gumbel_from_word(wd);
+                    }
                 }
             } else {
                 for (int b = 0; b < bx; ++b) {
@@ -411,6 +447,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             st_active = row >= 0 && lt >= 0 && lt < len;
             st_first = lt == 0;
             st_lt = lt; st_utt = utt;
+            if (BXT == 4 && cu == 0) { sinfo[cb * 2] = lt; sinfo[cb * 2 + 1] = (int)utt; }
             if (st_active) {
                 if (fpos == p.upsample) { fpos = 0; fidx += 1; }
                 if (fpos == 0 && cu < UPB) {                         // next conditioning frame (once per hop)
@@ -475,13 +512,9 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                 if (p.mulaw) p.mulaw[(size_t)st_erow * p.Lout + st_eidx] = x;
             }
             advance(t + 1);
-            float4 w1p[8];                                               // the first weights of what follows barrier A, requested in front of it
-            if constexpr (BXT == 4) {
-                w1p[0] = sv == 0 ? wp1[0] : wpx[0]; w1p[1] = sv == 0 ? wp1[64] : wpx[32];
-            } else {
+            float4 w1p[BXT == 4 ? 2 * XD_DEPTH : 8];                      // the first weights of what follows barrier A, requested in front of it
 #pragma unroll
-                for (int i = 0; i < 8; ++i) w1p[i] = wp1[64 * i];
-            }
+            for (int i = 0; i < (BXT == 4 ? 2 * XD_DEPTH : 8); ++i) w1p[i] = (BXT == 4 && sv == 1) ? wpx[32 * i] : wp1[64 * i];      // four slots: wave 1 runs W_hh rows 80..83
             XD_SWEEP_H();
             XD_STAMP(0, 3);
             XD_BARRIVE();
@@ -493,9 +526,13 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             if constexpr (BXT == 4) {
                 // ---- four slots: the matrix pipe takes them together (ar_chain.h), so the two waves split the ROWS instead of the slots:
                 // wave 0 fc1 (the step's critical path: a_t goes out first), wave 1 W_hh rows 80..83
-                const float4 wpre[2] = {w1p[0], w1p[1]};
                 if (sv == 0) {
-                    const v4f a4 = chain_mfma_lds<64>(wp1, wpre, opm);
+                    const v4f a4 = chain_mfma_lds<64, XD_DEPTH>(wp1, w1p, opm);
+                    XD_STAMP(0, 14);
+#ifdef VQCPC_XD_STAMPS
+                    { const int done = __builtin_amdgcn_readfirstlane(__float_as_int(a4[0])); asm volatile("" :: "s"(done)); }      // the last term's RESULT is there
+                    XD_STAMP(0, 15);
+#endif
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = chain_combine(a4[i]);                  // fc1 row 4 rq + i of slot j
@@ -503,8 +540,11 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
                         v = v > 0.f ? v : 0.f;
                         if (sum_lane && (int)j < bx) xd_put(ga, (((unsigned)(rank * BXT) + j) << 3) * 8u + (4u * rq + (unsigned)i) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
                     }
+#if XD_HOLD
+                    if (lane == 0) __hip_atomic_store(s_ctl + 5, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // a_t is out: waves 4 and 8 may start
+#endif
                 } else {
-                    const v4f a4 = chain_mfma_lds<32>(wpx, wpre, opm);     // both half waves run the same 32 lane-chains; the lower half's results count
+                    const v4f a4 = chain_mfma_lds<32, XD_DEPTH>(wpx, w1p, opm);     // both half waves run the same 32 lane-chains; the lower half's results count
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float v = chain_combine(a4[i]);
@@ -541,7 +581,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
             }
             XD_STAMP(0, 7);
             XD_STAMP(1, 11);
-            draw_noise(t + 1);                                           // idle time: the candidates are still on their way
+            if (BXT != 4) draw_noise(t + 1);                             // idle time: the candidates are still on their way (four slots: wave 11 draws)
             XD_STAMP(0, 13);
             // ---- x_t: the slot's 32 candidates (tag t + 1, from the chain waves' fc2), picked up BEFORE barrier B
             __builtin_amdgcn_s_setprio(3);
