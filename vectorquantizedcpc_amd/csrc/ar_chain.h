@@ -226,8 +226,13 @@ __device__ __forceinline__ float chain_combine(float acc) {
     const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
     const float o = __uint_as_float(sw[1]);                                                        // rows 0 and 2: lane + 16
     const float q = acc + o;
-    const float q1 = PS_DPP(q, 0x104), q2 = PS_DPP(q, 0x108), q3 = PS_DPP(q, 0x10C);               // row_shl:4 / 8 / 12
-    return ((q + q1) + q2) + q3;
+    // ((q + q1) + q2) + q3, q_k = q of lane + 4 k: three v_add_f32_dpp (the shifted operand read in place) instead of three dpp moves and
+    // three adds; s_nop 1: the two wait states between the add that wrote q and its first dpp read (hipcc does not look into the statement)
+    float s;                                            // early clobber: q must stay what the second and third add shift
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:12 row_mask:0xf bank_mask:0xf" : "=&v"(s) : "v"(q));
+    return s;
 }
 
 // position of operand column k in the LDS copy (inverse of chain_col): chain cid = 2 kw + c0 at cid * stride, term n at phase_pos(n)

@@ -97,7 +97,7 @@ extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
 #define XD_NAP 42
 #endif
 #ifndef XD_HOLD
-#define XD_HOLD 0
+#define XD_HOLD 1
 #endif
 
 namespace {
