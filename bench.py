@@ -355,9 +355,14 @@ def cpu_baseline(n_utt):
 # ------------------------------------------------------------------------------------------
 PATH_NAMES = {0: "the launch-per-step kernels", 2: "the per-XCD resident decoders (ar_xcd_kernel)",
               3: "the matrix-core per-XCD resident decoders (ar_xcm_kernel)"}
-# what bounds the dominant kernel of each decode path.  ar_xcd_kernel issues NO MFMA instruction: its step is fp32 vector issue on
-# two service waves + three in-XCD exchange latencies; it is priced against the fp32 vector peak, which equals the fp32 MFMA peak.
-BOUND = {0: "mfma", 2: "valu", 3: "mfma"}
+# what bounds the dominant kernel of each decode path.  ar_xcd_kernel<4> (17..32 slots: the bench workload) runs its W_hh / fc1 chains on
+# the matrix pipe (v_mfma_f32_4x4x1_16B_f32); with one or two slots per XCD (<= 16 utterances) the kernel issues NO MFMA instruction and
+# is priced against the fp32 vector peak, which equals the fp32 MFMA peak (157.3 TFLOP/s).
+BOUND = {0: "mfma", 2: "mfma", 3: "mfma"}
+
+
+def xcd_bound(slots):
+    return "mfma" if slots > 16 else "valu"
 
 
 def synthetic_manifest(n, seed=synth.SEED):
@@ -460,13 +465,20 @@ def gru_roofline(voc, n_utt, step_us, n_steps=0, samples_per_utt=0):
         launch_us = step_us * steps
         flop = FLOP_PER_SAMPLE * n_utt * per_utt
         step_tflops = flop / (launch_us * 1e-6) / 1e12
-        return {"bound": BOUND[path],
-                "bound_detail": ("fp32 vector issue of two service waves per CU + three in-XCD exchange latencies per sample step; the kernel "
-                                 "issues no MFMA instruction and is priced against the fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s)")
-                                if path == 2 else "fp32 MFMA issue (5.1 us of a 10.3 us step) + three in-XCD exchange latencies per sample step",
+        slots = voc.last_slots()
+        four = path == 2 and slots > 16
+        return {"bound": (xcd_bound(slots) if path == 2 else BOUND[path]),
+                "bound_detail": (("the serial chain of a sample step (cell update -> h_t exchange -> fc1 -> a_t exchange -> fc2 -> candidate exchange -> "
+                                  "x_t: ~2.5 of 3.7 us) with the fp32 matrix pipe busy 1.2 us per SIMD and step (336 v_mfma_f32_4x4x1_16B_f32)")
+                                 if four else
+                                 ("fp32 vector issue + three in-XCD exchange latencies per sample step; with one or two slots per XCD the kernel "
+                                  "issues no MFMA instruction and is priced against the fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s)"))
+                                if path == 2 else "fp32 MFMA issue (4.7 us of a 10.3 us step) + three in-XCD exchange latencies per sample step",
                 "kernel": ("ar_xcd_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD -- W_hh in VGPRs, fc1 / fc2 / "
-                           "embedding table in LDS, h_t / a_t / candidates exchanged through the XCD's own L2; fp32 VALU fma chains, "
-                           "bit-identical to the MFMA kernels)") if path == 2 else
+                           "embedding table in LDS, h_t / a_t / candidates exchanged through the XCD's own L2; the fp32 fma chains of the "
+                           + ("four slots of an XCD as v_mfma_f32_4x4x1_16B_f32 (one instruction per term for 4 rows x 4 slots), "
+                              if four else "slots as v_fmac_f32_dpp, ") +
+                           "bit-identical to the MFMA kernels of the other paths)") if path == 2 else
                           ("ar_xcm_kernel (ONE launch per call: a resident, weight-stationary decoder per XCD for 16 decode slots -- "
                            "[W_hh; W_fc1] h_t as six v_mfma_f32_16x16x4_f32 tiles per workgroup with the A fragments pinned in VGPRs, "
                            "fc2 fragments in LDS, h_t / a_t / candidates exchanged through the XCD's own L2)"),

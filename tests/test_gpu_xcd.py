@@ -54,11 +54,14 @@ def test_same_samples_as_the_launch_path(B, Tc, ragged):
     assert int((out[1][1] != 0).sum()) > 0.9 * 320 * sum(n_codes or [Tc] * B)
 
 
-def test_draw_by_draw_against_the_oracle():
+@pytest.mark.parametrize("B", [5, 20])
+def test_draw_by_draw_against_the_oracle(B):
+    """B = 5: one slot per XCD (fp32 vector chains); B = 20: up to three slots per XCD = the four-slot kernel, whose W_hh / fc1 chains run
+    on the matrix pipe (v_mfma_f32_4x4x1_16B_f32, ar_chain.h) with one column idle."""
     voc, sd = vocoder()
     voc.set_option("xcd", 1)
     try:
-        B, Tc, steps = 5, 2, 480
+        Tc, steps = 2, 480
         z = synth.randint("xcd/oz", (B, Tc), 512)
         spk = synth.randint("xcd/os", (B,), 102)
         wav, mu = voc.generate(z.cuda(), spk.cuda(), seed=13, utt_base=11, return_mulaw=True, max_steps=steps)
@@ -158,7 +161,7 @@ def _reference_bits(z, spk, **kw):
     return wav.cpu(), mu.cpu()
 
 
-@pytest.mark.parametrize("B", [1, 12])
+@pytest.mark.parametrize("B", [1, 12, 20])
 def test_xcd_handoff_timeout_is_reported_by_the_same_call_and_the_rerun_is_right(B):
     """One worker skips a candidate publish: every wait behind it gives up after the (shortened) deadline, check() raises
     for THAT call, the handle falls back to launches, and the repeated call gives the samples of the undisturbed paths."""

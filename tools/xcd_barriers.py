@@ -41,10 +41,15 @@ for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 32]:
     s = s[1:] - t0[:-1, None, None]
     print(f"per-XCD decoders ({os.path.relpath(_lib.LIB_PATH, ROOT)}), {B} utterance(s): {ms * 1e3 / n:.2f} us per sample step over the call; "
           f"step by these stamps {step.mean():.2f}; us after the last wave left the previous step's barrier B, mean over {len(s)} steps")
-    print("  wave  role                     arrives at A  leaves A   arrives at B  leaves B")
+    print("  wave  role                         arrives at A  leaves A   arrives at B  leaves B")
     for w in range(12):
-        role = "service" if w < 2 else ("chain + fc2 of slot %d" % (w - 2) if w - 2 < max(1, min(4, B // 8)) else "chain")
-        if B <= 8 and w == 1:
-            role = "fc1 (one slot)"
+        if B > 16:          # four slots per XCD: the chains run on the matrix pipe; fc2 on waves 2, 3, 6, 7; waves 4 and 8 wait for a_t to go out
+            role = {0: "service + fc1", 1: "service + W_hh rows 80..83", 2: "chain + fc2 of slot 0", 3: "chain + fc2 of slot 1",
+                    6: "chain + fc2 of slot 2", 7: "chain + fc2 of slot 3", 4: "chain, held behind fc1", 8: "chain, held behind fc1",
+                    11: "chain + next step's noise"}.get(w, "chain")
+        else:
+            role = "service" if w < 2 else ("chain + fc2 of slot %d" % (w - 2) if w - 2 < max(1, B // 8) else "chain")
+            if B <= 8 and w == 1:
+                role = "fc1 (one slot)"
         m = s[:, w, :].mean(axis=0)
-        print(f"  {w:4d}  {role:24s} {m[0]:10.2f} {m[1]:10.2f} {m[2]:12.2f} {m[3]:10.2f}")
+        print(f"  {w:4d}  {role:28s} {m[0]:10.2f} {m[1]:10.2f} {m[2]:12.2f} {m[3]:10.2f}")
