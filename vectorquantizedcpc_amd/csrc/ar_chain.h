@@ -273,11 +273,13 @@ __device__ __forceinline__ void chain_mfma_regs(v4f &acc, const float *w, const 
 #pragma unroll
     for (int g = G0; g < G1; ++g) {
         nxt[0] = cur[0]; nxt[1] = cur[1];
-        if (g + 1 < NG_H) { nxt[0] = *(const float4 *)(op + 8 * (g + 1)); nxt[1] = *(const float4 *)(op + 8 * (g + 1) + 4); }
-        __builtin_amdgcn_sched_barrier(0);
         const float hv[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[8 * g + i], hv[i], acc, 0, 0, 0);
+        // the next group's operands are requested BEHIND this group's terms (in front of them: 3.73 instead of 3.69 us per step at 32
+        // utterances): three waves share the pipe, the read comes back while the other two run their groups
+        if (g + 1 < NG_H) { nxt[0] = *(const float4 *)(op + 8 * (g + 1)); nxt[1] = *(const float4 *)(op + 8 * (g + 1) + 4); }
         __builtin_amdgcn_sched_barrier(0);
         cur[0] = nxt[0]; cur[1] = nxt[1];
     }

@@ -59,8 +59,15 @@ constexpr int FPB = 8;                 // fc1 rows / fc2 classes per workgroup
 constexpr int THREADS = 768;
 constexpr int BX = XM_BX;              // decode slots per XCD = columns of an MFMA tile
 constexpr int LROWS = 96;              // rows of a workgroup: 84 of W_hh [gate][unit], 8 of fc1, 4 of padding
-constexpr int HSD = HR + 4;            // slot stride of h_t in LDS (floats): 16 slots x 16 bytes hit 64 different banks
-constexpr int ASD = HF + 4;
+// Slot strides of h_t / a_t in LDS (floats): 2 units of 16 bytes mod 16.  A B fragment is read by ds_read_b128 with lane = (slot, aq) at
+// 16-byte unit S slot + aq (+ const); the instruction's four lane groups ({0-3, 12-15, 20-27}, ...) each hold all 16 slots, half of them
+// with aq one higher: with S = 1 (stride HR + 4, rounds 3 and 4 until the SQ counters were read) two lanes of every group met on one
+// unit -- SQ_LDS_BANK_CONFLICT 0.43 of the LDS cycles of the whole kernel (profiles/r04_pmc_sq_xcm128.json); S = 2 puts the sixteen lanes
+// on sixteen units.  The sweeps store slots s and s + 8 from one exchange chunk (XM_SLOT: the exchange arrays pair them), 8 and 264 floats
+// = 8 banks apart: 2-way on ds_write_b32, which costs nothing.
+constexpr int HSD = HR + 8;
+constexpr int ASD = HF + 8;
+#define XM_SLOT(s) (2u * ((s) & 7u) + ((s) >> 3))     // position of slot s in a 16-slot row of the h_t / a_t exchange arrays
 constexpr int CELLS = UPB * BX;        // cell-update threads: (unit, slot)
 constexpr int BOOK = 11;               // the wave that keeps the slots' books (the youngest: it has nothing else to do behind its MFMAs)
 
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                     hn = (1.0f - z) * nn + z * hold;
                     hprev = hn;
                 }
-                xd_put(gh, ((unsigned)(UPB * rank + cu) * BX + cs) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
+                xd_put(gh, ((unsigned)(UPB * rank + cu) * BX + XM_SLOT(cs)) * 8u, ((u64)tag << 32) | __float_as_uint(hn), agent);
             }
         }
         XM_STAMP(0, 1);
@@ -391,8 +398,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 const unsigned L = td + 768u * (5 * rnd + i);
                 if (L < (unsigned)(XM_H / 2)) {
                     const unsigned k = L >> 3, pr = L & 7u;
-                    hT[(2 * pr) * HSD + k] = __uint_as_float(v[i].x);
-                    hT[(2 * pr + 1) * HSD + k] = __uint_as_float(v[i].z);
+                    hT[pr * HSD + k] = __uint_as_float(v[i].x);                 // chunk pr of a column: slots pr and pr + 8
+                    hT[(pr + 8) * HSD + k] = __uint_as_float(v[i].z);
                 }
             }
         }
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                         float v = ((qA[i] + pr[Q + i * BX]) + pr[2 * Q + i * BX]) + pr[3 * Q + i * BX];
                         v += bqs[96 + f];
                         v = v > 0.f ? v : 0.f;
-                        xd_put(ga, ((unsigned)(FPB * rank + f) * BX + arow) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
+                        xd_put(ga, ((unsigned)(FPB * rank + f) * BX + XM_SLOT(arow)) * 8u, ((u64)tag << 32) | __float_as_uint(v), agent);
                     }
                 }
                 XM_STAMP(0, 5);
@@ -483,8 +490,8 @@ __global__ __launch_bounds__(THREADS) void ar_xcm_kernel(XdParams p) {
                 for (int i = 0; i < 8; ++i) {
                     const unsigned c = ln + 64u * i;
                     const unsigned r = 64u * wave + (c >> 3), pr = c & 7u;
-                    aT[(2 * pr) * ASD + r] = __uint_as_float(v[i].x);
-                    aT[(2 * pr + 1) * ASD + r] = __uint_as_float(v[i].z);
+                    aT[pr * ASD + r] = __uint_as_float(v[i].x);
+                    aT[(pr + 8) * ASD + r] = __uint_as_float(v[i].z);
                 }
             }
             XM_STAMP(0, 6);
