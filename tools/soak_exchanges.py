@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the in-kernel exchange paths for ~60 s: the resident context scan (encode of one utterance), the per-XCD resident
-decoders at 1, 12 and 32 utterances (one, two and four slots per XCD), their matrix-core form at 100 utterances and at 150
+decoders at 1, 12 and 32 utterances (one, two and four slots per XCD; four slots = the chains on the matrix pipe, fc1's SIMD mates
+held behind an LDS flag), 45 ragged utterances through the 32 slots (slot hand-over), their 16-slot matrix-core form at 100 utterances and at 150
 utterances through its 128 slots, and the fused fc2 || GRU launches (`xcd` = 0), every result compared bit for bit with the
 first round's and every call followed by check().
 
@@ -27,13 +28,13 @@ mel = synth.mel("soak/mel", 1, 200).cuda()
 z0, c0, i0 = enc.encode(mel)
 enc.check()
 cases = []
-for name, B, Tc, opts in (("xcd 1", 1, 12, {}), ("xcd 12", 12, 6, {}), ("xcd 32", 32, 6, {}), ("xcm 100", 100, 4, {}),
+for name, B, Tc, opts in (("xcd 1", 1, 12, {}), ("xcd 12", 12, 6, {}), ("xcd 32", 32, 6, {}), ("xcd 45 ragged", 45, 5, {}), ("xcm 100", 100, 4, {}),
                           ("xcm 150 ragged", 150, 4, {}), ("launches 32", 32, 6, {"xcd": 0})):
     z = synth.randint("soak/z" + name, (B, Tc), 512).cuda()
     spk = (torch.arange(B) % 102).cuda()
     n_codes = [1 + (3 * b) % Tc for b in range(B)] if "ragged" in name else None
     cases.append((name, z, spk, n_codes, opts, None))
-want_path = {"xcd 1": 2, "xcd 12": 2, "xcd 32": 2, "xcm 100": 3, "xcm 150 ragged": 3, "launches 32": 0}
+want_path = {"xcd 1": 2, "xcd 12": 2, "xcd 32": 2, "xcd 45 ragged": 2, "xcm 100": 3, "xcm 150 ragged": 3, "launches 32": 0}
 ref = {}
 t0 = time.time()
 n = 0
