@@ -58,6 +58,15 @@ for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 16, 32]:
         ("service wave 0: x_t known -> past barrier B", a[:, 12] - a[:, 1]),
         ("whole step", b[:, 0] - a[:, 0]),
     ]
+    if B > 16:      # four slots per XCD: the matrix-pipe form -- wave 0 runs fc1 of all four slots, wave 1 W_hh rows 80..83, wave 11 draws the noise
+        relabel = {"service wave 0: barrier A -> fc1 rows of its slots published": "service wave 0: barrier A -> a_t of the four slots published (fc1 chain + combine, bias, ReLU, stores)",
+                   "service wave 1: barrier A -> fc1 rows of its slots published": "service wave 1: barrier A -> W_hh rows 80..83 of the four slots in LDS",
+                   "service wave 0: fc1 published -> W_hh rows 80..83 of the other wave's slots done": "service wave 0: a_t published -> (nothing of its own; two stamps among the released chain waves' matrix instructions)",
+                   "service wave 1: fc1 published -> W_hh rows 80..83 of the other wave's slots done": "service wave 1: rows in LDS -> (nothing of its own; two stamps)",
+                   "service wave 0: W_hh rows done -> noise of the next step drawn": "service wave 0: -> candidate poll begins (no noise to draw: wave 11 does)",
+                   "chain wave 0: barrier A -> a_t of its slot gathered (after its first W_hh chains)": "chain wave 0: barrier A -> a_t of slot 0 gathered (behind 10 of its chain's 14 groups)",
+                   "chain wave 0: candidate published -> all its W_hh chains done": "chain wave 0: candidate published -> the rest of its chain done"}
+        rows = [(relabel.get(n, n), d) for n, d in rows]
     print(f"per-XCD decoders, {B} utterance(s): {ms * 1e3 / n:.2f} us per sample step over the call; worker 5 of XCD 0, "
           f"mean / min / max over 116 steps, us")
     for name, d in rows:
