@@ -15,9 +15,12 @@
 //     touches any output, and the host falls back to the launch-per-step kernels.
 // Arithmetic is bit-identical to those kernels: a row's dot product is the same 8 fp32 fma chains (K quarter x x/z|y/w
 // accumulator: ar_shared.h), combined in the same order; cell update, fc epilogues and the Gumbel-max draw are the
-// same expressions.  A chain lives in ONE lane; the four lanes of a quad hold the same chain of four different rows and
-// share its operand values (each lane loads a quarter of h from LDS, v_fmac_f32_dpp quad_perm broadcasts them), which
-// cuts the LDS operand traffic by 4 and leaves the step VALU-bound.
+// same expressions.  A chain lives in ONE lane; the four lanes of a quad hold the same chain of four different rows.
+// With ONE or TWO slots per XCD (ar_xcd_kernel<1>, <2>) the quad shares a chain's operand values (each lane loads a quarter of
+// h from LDS, v_fmac_f32_dpp quad_perm broadcasts them): a quarter of the LDS operand traffic, one vector instruction per term,
+// row and slot.  With FOUR slots per XCD (ar_xcd_kernel<4>, 17..32 utterances) the same chains run on the matrix pipe:
+// v_mfma_f32_4x4x1_16B_f32 advances a quad's four rows for the four slots in one instruction (ar_chain.h) -- the vector form was
+// vector-ALU bound between the barriers at four slots (3.5 of 5.1 us; profiles/r04_ablation.txt, r04_mfma_chains.txt).
 //
 // Roles of the 12 waves of a workgroup (the two service waves are waves 0 and 1, the OLDEST of their SIMDs: the instruction
 // arbiter serves the oldest wave first -- ar_xcm.hip has the measurements -- and what they do is the critical path; as waves
@@ -33,6 +36,11 @@
 //                next step's Gumbel noise (Philox + two logs per class); x_t from the slot's 32 candidates, picked up
 //                before barrier B
 //   all waves    sweep h_t into LDS
+// Four slots per XCD, what differs: every wave runs ONE dependent chain of 112 matrix instructions per step (waves 2..11 rows
+// 0..79 with pinned weights, wave 0 fc1 for all four slots and wave 1 W_hh rows 80..83, both with weights streamed from LDS);
+// fc2 + draw of slots 0..3 on waves 2, 3, 6, 7; waves 4 and 8 -- fc1's SIMD mates -- start their chains when a_t is out (two
+// dependent-chain waves keep a SIMD's issue port ~80 % busy, whatever s_setprio says); wave 11 draws the next step's noise
+// behind its chain from the slots' clocks the service waves post in LDS.
 // Two workgroup barriers per sample.  Every wait is wall-clock bounded; a timeout sets status bit 0, every workgroup
 // leaves, and the call's outputs are incomplete (vqcpc_vocoder_check reports it).
 #include "ar_xcd.h"

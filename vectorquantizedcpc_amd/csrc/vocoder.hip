@@ -1374,7 +1374,7 @@ struct vqcpc_vocoder {
     int xcd_debug_drop_step = -1;        // tests: one worker skips a candidate publish at this step -> the waits time out
     // the same decoders on the matrix cores, 16 slots per XCD (ar_xcm.hip): -1 auto (more than xcm_min and fewer than xcm_max
     // utterances in flight), 0 never, 1 whenever the dimensions allow.  Measured (tools/xcm_probe.py, bench_by_batch): 10.3 us
-    // per step whatever the number of slots in use -> 6.2 M samples/s at 64 utterances (VALU form through 32 slots: 6.5 M),
+    // per step whatever the number of slots in use -> 6.2 M samples/s at 64 utterances (ar_xcd.hip through its 32 slots: 8.5 M),
     // 12.3 M at 128 and 256 (launches: 8.2 / 10.8 M), against 12.4 M on the launch path with 512 utterances in flight.
     int xcm = -1;
     int xcm_min = 68, xcm_max = 512;
@@ -1848,9 +1848,9 @@ static bool plan_decode(const PlanOpts &o, const int *samples, const unsigned *u
     long max_len = 0;
     for (int row : order) { nz += samples[row] > 0; max_len = samples[row] > max_len ? samples[row] : max_len; }
     pl = DecodePlan{};
-    // auto: up to xcm_min (68) utterances in flight the VALU form (6.5 M samples/s through its 32 slots at 32 and 64 utterances
-    // against 3.4 / 4.7 M on the launch path), from there to xcm_max the matrix-core form through its 128 slots, above that the
-    // launch-per-step kernels; `xcd` = 0 turns both off, = 1 asks for the VALU form whatever the count
+    // auto: up to xcm_min (68) utterances in flight ar_xcd.hip (8.5 M samples/s through its 32 slots at 32 and 64 utterances
+    // against 3.4 / 4.7 M on the launch path), from there to xcm_max the 16-slot matrix-core form through its 128 slots (9.3 M at 96,
+    // 12.4 M from 128), above that the launch-per-step kernels; `xcd` = 0 turns both off, = 1 asks for ar_xcd.hip whatever the count
     const int in_flight = o.n_slots > 0 && o.n_slots < nz ? o.n_slots : nz;
     const bool xcm_wanted = o.xcd != 0 && (o.xcm == 1 || (o.xcm == -1 && o.xcd == -1 && in_flight > o.xcm_min && in_flight < o.xcm_max));
     const bool xcd_wanted = xcm_wanted || o.xcd == 1 || (o.xcd == -1 && in_flight <= o.xcm_min);
