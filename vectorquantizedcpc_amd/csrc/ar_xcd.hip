@@ -101,9 +101,6 @@ extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
 #ifndef XD_DEPTH
 #define XD_DEPTH 3
 #endif
-#ifndef XD_NAP
-#define XD_NAP 42
-#endif
 #ifndef XD_HOLD
 #define XD_HOLD 1
 #endif
@@ -200,6 +197,7 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
     for (unsigned e = tid; e < NC; e += THREADS) mtab[e] = p.mulaw_tab[e];
     for (unsigned e = tid; e < 96; e += THREADS) { const unsigned g = e >> 5, u = e & 31; c_bq[e] = u < UPB ? p.b_hh[g * HR + UPB * rank + u] : 0.f; }
     for (unsigned e = tid; e < BXT * 96; e += THREADS) gsum[e] = 0.f;
+    for (unsigned e = tid; e < BXT * L::HS; e += THREADS) hc[e] = 0.f;     // four slots: the matrix instruction multiplies all four columns, also those of slots this XCD does not run
     for (unsigned e = tid; e < BXT; e += THREADS) {
         const XdSeg sg = (int)e < bx ? p.segs[(size_t)(xcc + 8 * e) * p.max_seg] : XdSeg{-1, 0, 0, 0u};
         seg_st[e * 8 + 0] = 0; seg_st[e * 8 + 1] = sg.len > 0 ? sg.row : -1; seg_st[e * 8 + 2] = sg.t0; seg_st[e * 8 + 3] = sg.len;
@@ -364,8 +362,6 @@ __global__ __launch_bounds__(THREADS) void ar_xcd_kernel(XdParams p) {
 #if XD_HOLD
                 if ((wave & 3) == 0)
                     while (__hip_atomic_load(s_ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)tag) __builtin_amdgcn_s_sleep(2);
-#elif XD_NAP > 0
-                if ((wave & 3) == 0) __builtin_amdgcn_s_sleep(XD_NAP);
 #endif
                 chain_mfma_regs<0, XD_GSPLIT>(a4, w, opm, cur);
                 if (fc2_wave) fc2_and_draw();
