@@ -89,7 +89,7 @@ extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
 // Ablation of the exchange WAITS, for timing only (results are garbage: stale granules are used as they are found): bit 0 the
 // candidate poll, bit 1 the a_t poll, bit 2 the h_t sweep take whatever their first load returns.  What a step still costs then
 // is what the workgroup's own instruction streams, LDS traffic, L2 round trips and barriers cost -- profiles/r04_ablation.txt.
-// Never set in the shipped library (tools/build_stamps.sh "-DVQCPC_XD_STAMPS -DXD_ABLATE=7").
+// Never set in the shipped library (tools/build_variant.sh A7 "-DXD_ABLATE=7"; tools/ab_libs.py times the builds).
 #ifndef XD_ABLATE
 #define XD_ABLATE 0
 #endif
@@ -101,6 +101,7 @@ extern "C" int vqcpc_debug_xd_bars(unsigned long long *out) {
 #ifndef XD_DEPTH
 #define XD_DEPTH 3
 #endif
+// four slots per XCD: the two chain waves on fc1's SIMD start their chains when a_t is out (0: at once -- A/B builds, profiles/r04_mfma_chains.txt)
 #ifndef XD_HOLD
 #define XD_HOLD 1
 #endif
